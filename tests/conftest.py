@@ -1,0 +1,33 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+PKG = os.path.join(ROOT, "web-rwkv-gguf_amd")
+if PKG not in sys.path:
+    sys.path.insert(0, PKG)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _has_gpu() -> bool:
+    return os.path.exists("/dev/kfd")
+
+
+@pytest.fixture(scope="session")
+def has_gpu():
+    return _has_gpu()
+
+
+def pytest_collection_modifyitems(config, items):
+    if _has_gpu():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container (/dev/kfd absent)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
