@@ -1,0 +1,121 @@
+"""CPU-side tests of the C-ABI libraries and the native host layer (no GPU needed).
+
+ * every function declared in include/*.h is exported by the built library;
+ * the host GGUF reader / loader (C++) agrees bit-for-bit with the oracle restatement;
+ * the C++ chunk scheduler reproduces the reference's known-answer tests (rnn.rs:363-569);
+ * the HIP path fails loudly without a device (no CPU fallback).
+"""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import wrk
+from oracle import gguf as ogguf
+from oracle import rwkv7 as orwkv7
+from oracle import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(wrk_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported():
+    for header, lib, table in (("wrk_hip.h", wrk.hip, wrk.HIP_SYMBOLS), ("wrk_runtime.h", wrk.rt, wrk.RT_SYMBOLS)):
+        names = _declared(header)
+        assert len(names) > 20
+        for n in names:
+            assert hasattr(lib, n), f"{n} declared in {header} but not exported"
+            assert n in table, f"{n} has no ctypes signature"
+        assert sorted(table) == names
+    assert wrk.hip.wrk_abi_version() == 1
+
+
+def test_no_gpu_means_loud_failure(has_gpu):
+    if has_gpu:
+        pytest.skip("GPU present")
+    with pytest.raises(wrk.WrkError):
+        wrk.Context(0)
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    data = synth.make_v7_gguf(synth.CONFIGS["tiny"], 42, mat_override={"time_mix_value": "Q5_K", "channel_mix_value": "Q8_0"})
+    return data, ogguf.GgufReader(data), wrk.GgufReader(data)
+
+
+def test_host_reader_matches_oracle(tiny):
+    data, oref, r = tiny
+    assert r.version == oref.version and r.tensor_data_offset == oref.tensor_data_offset
+    names = ["emb.weight", "head.weight", "blocks.0.ln0.weight", "blocks.1.att.x_a", "blocks.0.att.r_k", "blocks.1.att.w1",
+             "blocks.0.att.key.weight", "blocks.1.att.value.weight", "blocks.1.ffn.value.weight", "blocks.0.ffn.key.weight",
+             "blocks.1.att.time_maa", "blocks.0.att.ln_x.bias"]
+    for n in names:
+        assert r.contains(n) == oref.contains(n) is True
+        assert r.shape(n) == oref.shape(n), n
+        got = r.tensor_f16(n).astype(np.float32)
+        _, _, want = oref.tensor(n)
+        want = want.astype(np.float16).astype(np.float32)     # tensor_f16_from_reader
+        assert got.shape == want.shape and np.array_equal(got, want), n
+    assert not r.contains("blocks.7.att.x_r")
+    with pytest.raises(wrk.WrkError):
+        r.shape("nope")
+    t, raw = r.raw("blocks.1.att.value.weight")
+    assert t == 13 and np.array_equal(raw, oref.raw_tensor("blocks.1.att.value.weight")[1])
+
+
+def test_host_info_matches_oracle(tiny):
+    _, oref, r = tiny
+    a, b = r.info(), orwkv7.loader_info(oref)
+    assert (a.version, a.num_layer, a.num_emb, a.num_hidden, a.num_vocab, a.num_head) == (7, b.num_layer, b.num_emb, b.num_hidden, b.num_vocab, b.num_head)
+    assert {"w": a.lora_w, "a": a.lora_a, "g": a.lora_g, "v": a.lora_v} == b.custom
+
+
+def test_host_reader_rejects_bad_files():
+    for bad in (b"XXXX" + b"\0" * 64, b"GGUF" + (9).to_bytes(4, "little") + b"\0" * 64, b"GGUF" + (3).to_bytes(4, "little") + (5).to_bytes(8, "little") + (0).to_bytes(8, "little")):
+        with pytest.raises(wrk.WrkError):
+            wrk.GgufReader(bad)
+    # a tensor table that points outside the file must be refused before anything is uploaded
+    data = bytearray(synth.make_v7_gguf(synth.CONFIGS["tiny"], 42))
+    with pytest.raises(wrk.WrkError):
+        wrk.GgufReader(bytes(data[: len(data) // 2]))
+
+
+L, F, N = wrk.RNN_LAST, wrk.RNN_FULL, wrk.RNN_NONE
+
+
+def _inp(lens_opts, chunk):
+    return wrk.RnnInput([[i] * n for i, (n, _) in enumerate(lens_opts)], chunk, [o for _, o in lens_opts])
+
+
+def test_scheduler_known_answers():
+    """Data of rnn.rs:363-445 (test_run_iter) and :447-503 (test_advance)."""
+    it = _inp([(139, L), (1, L), (0, F), (65, F)], 128).iter()
+    assert next(it) == [(65, N), (1, L), (0, F), (62, F)]
+    assert next(it) == [(60, N), (1, L), (0, F), (3, F)]
+    assert next(it) == [(14, L), (1, L), (0, F), (1, F)]
+    assert next(it) == [(1, L), (1, L), (0, F), (1, F)]
+    assert next(it) == [(1, L), (1, L), (0, F), (1, F)]
+    run = _inp([(139, L), (1, L), (0, F), (65, F)], 128)
+    run.step()
+    assert next(run.iter()) == [(61, N), (0, L), (0, F), (3, F)]
+    assert next(_inp([(61, L), (1, L), (0, F), (3, F)], 128).iter()) == [(60, N), (1, L), (0, F), (3, F)]
+
+
+def test_redirect_known_answers():
+    """Data of rnn.rs:505-569 (test_redirect)."""
+    h, i, o = wrk.redirect(next(_inp([(61, L), (0, L), (0, F), (3, F)], 128).iter()))
+    assert h == [60, 61, 62, 63] and i == [(0, 61), (61, 61), (61, 61), (61, 64)] and o == [(0, 1), (1, 1), (1, 1), (1, 4)]
+    h, i, o = wrk.redirect(next(_inp([(11, L), (8, L), (9, L), (4, L)] * 2, 32).iter()))
+    assert h == [15, 31]
+    assert i == [(0, 4), (4, 8), (8, 12), (12, 16), (16, 20), (20, 24), (24, 28), (28, 32)]
+    assert o == [(0, 0), (0, 0), (0, 0), (0, 1), (1, 1), (1, 1), (1, 1), (1, 2)]
+
+
+def test_chunk_size_rounding():
+    assert _inp([(1, L)], 1).token_chunk_size == 32 and _inp([(1, L)], 33).token_chunk_size == 64

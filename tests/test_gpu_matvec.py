@@ -1,0 +1,94 @@
+"""GPU parity of the inline-dequant matvec (C ABI wrk_op_matmul) against the oracle dequantisers.
+
+The oracle dequantises with the reference's CPU routines (gguf.rs:11-274) and contracts in f64;
+the kernel accumulates exact f16 x f16 products in f32, so for f32 outputs
+  |got - want| <= 4e-6 * sum|w||x| + 1e-6        (f32 accumulation of K terms)
+and f16 outputs are within one f16 ulp.  WRK_MATRIX_ROUND_F16 is checked against weights rounded
+to f16 (the reference's effective path); the default mode against f32-exact weights.
+"""
+import numpy as np
+import pytest
+
+import wrk
+from oracle import dequant as dq
+from oracle import quantize as qz
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = wrk.Context(0)
+    yield c
+    c.close()
+
+
+def make(kind, k, m, seed):
+    r = np.random.default_rng(seed)
+    w = (r.standard_normal((m, k)) / np.sqrt(k)).astype(np.float32)
+    raw = qz.QUANTIZE[kind](w)
+    return raw
+
+
+CASES = [("Q4_K", 256, 7), ("Q4_K", 2048, 64), ("Q4_K", 2560, 33), ("Q4_K", 8192, 16),
+         ("Q5_K", 512, 9), ("Q5_K", 4096, 32), ("Q6_K", 256, 5), ("Q6_K", 2048, 130), ("Q6_K", 2560, 12),
+         ("Q8_0", 96, 10), ("Q8_0", 4096, 40), ("Q8_0", 64, 2048),
+         ("F16", 96, 2048), ("F16", 2048, 96), ("F16", 768, 100), ("F32", 256, 64)]
+
+
+@pytest.mark.parametrize("kind,k,m", CASES)
+@pytest.mark.parametrize("flags", [wrk.MATRIX_EXACT, wrk.MATRIX_ROUND_F16])
+def test_matvec_single_token(ctx, kind, k, m, flags):
+    raw = make(kind, k, m, k + m)
+    mat = wrk.Matrix(ctx, kind, k, m, raw, flags)
+    assert mat.stream_bytes == (raw.size if kind != "F32" else raw.size // 2)
+    w = dq.dequantize(kind, raw, k * m, round_f16=(flags == wrk.MATRIX_ROUND_F16 or kind == "F32")).reshape(m, k)
+    x = (np.random.default_rng(1).standard_normal(k)).astype(np.float16)
+    out = ctx.zeros([m, 1, 1], np.float32)
+    mat.matmul_op(ctx.tensor(x, [k, 1, 1]), out)
+    got = out.back().reshape(m)
+    want = w.astype(np.float64) @ x.astype(np.float64)
+    bound = 4e-6 * (np.abs(w).astype(np.float64) @ np.abs(x).astype(np.float64)) + 1e-6
+    assert np.all(np.abs(got - want) <= bound), np.abs(got - want).max()
+
+
+@pytest.mark.parametrize("kind,k,m", [("Q4_K", 2048, 48), ("Q6_K", 512, 20), ("Q5_K", 256, 8), ("Q8_0", 1024, 24), ("F16", 256, 40)])
+@pytest.mark.parametrize("T,B", [(2, 1), (3, 1), (5, 2), (9, 1), (1, 4)])
+def test_matvec_stacked_tokens_activation_f16_out(ctx, kind, k, m, T, B):
+    raw = make(kind, k, m, 3)
+    mat = wrk.Matrix(ctx, kind, k, m, raw)
+    w = dq.dequantize(kind, raw, k * m, round_f16=False).reshape(m, k)
+    x = np.random.default_rng(T * 7 + B).standard_normal((B, T, k)).astype(np.float16)
+    for act, fn in (("none", lambda z: z), ("squared_relu", lambda z: np.maximum(z, 0) ** 2), ("tanh", np.tanh),
+                    ("sigmoid", lambda z: 1 / (1 + np.exp(-z)))):
+        out = ctx.zeros([m, T, B])
+        mat.matmul_op(ctx.tensor(x), out, act)
+        got = out.back().reshape(B, T, m).astype(np.float32)
+        want = fn(x.astype(np.float64) @ w.astype(np.float64).T)
+        tol = np.maximum(np.abs(want), 2.0 ** -14) * 2.0 ** -10 + 2e-5
+        assert np.all(np.abs(got - want) <= tol), (act, np.abs(got - want).max())
+
+
+def test_matvec_view_offsets(ctx):
+    """Matrix::matmul_op on views: head rows of x into a slice of a wider output (v7.rs:1026-1031)."""
+    k, m, T = 256, 24, 4
+    raw = make("Q4_K", k, m, 11)
+    mat = wrk.Matrix(ctx, "Q4_K", k, m, raw)
+    w = dq.dequantize("Q4_K", raw, k * m, round_f16=False).reshape(m, k)
+    x = np.random.default_rng(5).standard_normal((T, k)).astype(np.float16)
+    out = ctx.zeros([m, T, 1], np.float32)
+    mat.matmul_op(ctx.tensor(x, [k, T, 1]).view(None, (1, 3)), out.view(None, (2, 4)))
+    got = out.back().reshape(T, m)
+    want = x[1:3].astype(np.float64) @ w.astype(np.float64).T
+    np.testing.assert_allclose(got[2:4], want, rtol=1e-4, atol=1e-5)
+    assert not got[:2].any()
+
+
+def test_matrix_create_rejects_bad_input(ctx):
+    with pytest.raises(wrk.WrkError):
+        wrk.Matrix(ctx, "Q4_K", 300, 4, np.zeros(144 * 4, np.uint8))          # K % 256 != 0 (loader.rs:824-827)
+    with pytest.raises(wrk.WrkError):
+        wrk.Matrix(ctx, "Q4_K", 256, 4, np.zeros(100, np.uint8))              # wrong byte count
+    mat = wrk.Matrix(ctx, "Q8_0", 64, 4, make("Q8_0", 64, 4, 1))
+    with pytest.raises(wrk.WrkError):
+        mat.matmul_op(ctx.zeros([32, 1, 1]), ctx.zeros([4, 1, 1]))            # K mismatch

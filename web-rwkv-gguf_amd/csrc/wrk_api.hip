@@ -1,0 +1,478 @@
+// C ABI: context, buffers, programs, matrices and the wrk_op_* TensorOp entry points
+// (include/wrk_hip.h).  Each function validates shapes the way the reference's TensorOp
+// constructors do (TensorError -> WRK_E_ARG) and enqueues the kernels of wrk_ops.hip /
+// wrk_matvec.hip on the context's stream.
+#include "wrk_internal.h"
+
+#include <memory>
+
+#define LOCK(ctx) std::lock_guard<std::recursive_mutex> _lk((ctx)->mu)
+
+extern "C" {
+
+int32_t wrk_abi_version(void) { return WRK_ABI_VERSION; }
+
+// ---------------------------------------------------------------- context
+int32_t wrk_ctx_create(int32_t device, wrk_ctx** out) {
+    if (!out) return WRK_E_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return WRK_E_HIP;   // no HIP device: fail loudly
+    if (device < 0 || device >= count) return WRK_E_ARG;
+    std::unique_ptr<wrk_ctx> ctx(new wrk_ctx());
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess) return WRK_E_HIP;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return WRK_E_HIP;
+    ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return WRK_E_HIP;
+    if (hipStreamCreateWithFlags(&ctx->read_stream, hipStreamNonBlocking) != hipSuccess) return WRK_E_HIP;
+    if (hipEventCreateWithFlags(&ctx->read_event, hipEventDisableTiming) != hipSuccess) return WRK_E_HIP;
+    *out = ctx.release();
+    return WRK_OK;
+}
+
+int32_t wrk_ctx_destroy(wrk_ctx* ctx) {
+    if (!ctx) return WRK_E_ARG;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    hipStreamSynchronize(ctx->read_stream);
+    if (ctx->staging) hipHostFree(ctx->staging);
+    hipEventDestroy(ctx->read_event);
+    hipStreamDestroy(ctx->read_stream);
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return WRK_OK;
+}
+
+const char* wrk_last_error(wrk_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int32_t wrk_ctx_sync(wrk_ctx* ctx) {
+    if (!ctx) return WRK_E_ARG;
+    LOCK(ctx);
+    WRK_HIP(ctx, hipSetDevice(ctx->device));
+    WRK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return WRK_OK;
+}
+
+void* wrk_ctx_stream(wrk_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+// ---------------------------------------------------------------- buffers
+int32_t wrk_buf_create(wrk_ctx* ctx, size_t bytes, const void* init, wrk_buf** out) {
+    if (!ctx || !out) return WRK_E_ARG;
+    LOCK(ctx);
+    *out = nullptr;
+    WRK_HIP(ctx, hipSetDevice(ctx->device));
+    void* p = nullptr;
+    const size_t alloc = bytes ? ((bytes + 255) & ~(size_t)255) : 256;
+    WRK_HIP(ctx, hipMalloc(&p, alloc));
+    if (init) {
+        hipError_t e = hipMemcpyAsync(p, init, bytes, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);     // source borrowed only for this call
+        if (e != hipSuccess) { hipFree(p); return wrk_fail(ctx, WRK_E_HIP, "upload: %s", hipGetErrorString(e)); }
+    } else {
+        hipError_t e = hipMemsetAsync(p, 0, alloc, ctx->stream);
+        if (e != hipSuccess) { hipFree(p); return wrk_fail(ctx, WRK_E_HIP, "memset: %s", hipGetErrorString(e)); }
+    }
+    wrk_buf* b = new wrk_buf{ctx, p, bytes, {1}};
+    *out = b;
+    return WRK_OK;
+}
+
+int32_t wrk_buf_retain(wrk_buf* buf) {
+    if (!buf) return WRK_E_ARG;
+    buf->refs.fetch_add(1);
+    return WRK_OK;
+}
+
+int32_t wrk_buf_release(wrk_buf* buf) {
+    if (!buf) return WRK_E_ARG;
+    if (buf->refs.fetch_sub(1) == 1) {
+        wrk_ctx* ctx = buf->ctx;
+        LOCK(ctx);
+        hipSetDevice(ctx->device);
+        hipStreamSynchronize(ctx->stream);      // no kernel may still reference it
+        hipFree(buf->ptr);
+        delete buf;
+    }
+    return WRK_OK;
+}
+
+size_t wrk_buf_size(const wrk_buf* buf) { return buf ? buf->bytes : 0; }
+void* wrk_buf_device_ptr(const wrk_buf* buf) { return buf ? buf->ptr : nullptr; }
+
+int32_t wrk_buf_write(wrk_ctx* ctx, wrk_buf* buf, size_t offset, const void* src, size_t bytes) {
+    if (!ctx || !buf || (!src && bytes)) return WRK_E_ARG;
+    LOCK(ctx);
+    WRK_ARG(ctx, offset + bytes <= buf->bytes, "wrk_buf_write: range %zu+%zu exceeds buffer of %zu bytes", offset, bytes, buf->bytes);
+    if (bytes == 0) return WRK_OK;
+    WRK_HIP(ctx, hipSetDevice(ctx->device));
+    // stream ordered; the source must be consumed before returning -> stage through pinned memory
+    if (ctx->staging_bytes < bytes) {
+        WRK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->staging) hipHostFree(ctx->staging);
+        ctx->staging = nullptr;
+        ctx->staging_bytes = 0;
+        size_t nb = bytes < (1u << 20) ? (1u << 20) : bytes;
+        WRK_HIP(ctx, hipHostMalloc(&ctx->staging, nb, hipHostMallocDefault));
+        ctx->staging_bytes = nb;
+    } else {
+        // the previous write may still be reading the staging area
+        WRK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    memcpy(ctx->staging, src, bytes);
+    WRK_HIP(ctx, hipMemcpyAsync((char*)buf->ptr + offset, ctx->staging, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return WRK_OK;
+}
+
+int32_t wrk_buf_read(wrk_ctx* ctx, const wrk_buf* buf, size_t offset, void* dst, size_t bytes) {
+    if (!ctx || !buf || (!dst && bytes)) return WRK_E_ARG;
+    {
+        LOCK(ctx);
+        WRK_ARG(ctx, offset + bytes <= buf->bytes, "wrk_buf_read: range %zu+%zu exceeds buffer of %zu bytes", offset, bytes, buf->bytes);
+        if (bytes == 0) return WRK_OK;
+        WRK_HIP(ctx, hipSetDevice(ctx->device));
+        // order the read after everything submitted so far, on the read-back stream
+        WRK_HIP(ctx, hipEventRecord(ctx->read_event, ctx->stream));
+        WRK_HIP(ctx, hipStreamWaitEvent(ctx->read_stream, ctx->read_event, 0));
+        WRK_HIP(ctx, hipMemcpyAsync(dst, (const char*)buf->ptr + offset, bytes, hipMemcpyDeviceToHost, ctx->read_stream));
+    }
+    WRK_HIP(ctx, hipStreamSynchronize(ctx->read_stream));       // blocking, outside the lock
+    return WRK_OK;
+}
+
+int32_t wrk_buf_copy(wrk_ctx* ctx, const wrk_buf* src, size_t so, wrk_buf* dst, size_t dof, size_t bytes) {
+    if (!ctx || !src || !dst) return WRK_E_ARG;
+    LOCK(ctx);
+    WRK_ARG(ctx, so + bytes <= src->bytes && dof + bytes <= dst->bytes, "wrk_buf_copy: out of range");
+    if (bytes == 0) return WRK_OK;
+    WRK_HIP(ctx, hipSetDevice(ctx->device));
+    WRK_HIP(ctx, hipMemcpyAsync((char*)dst->ptr + dof, (const char*)src->ptr + so, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return WRK_OK;
+}
+
+// ---------------------------------------------------------------- programs
+int32_t wrk_capture_begin(wrk_ctx* ctx) {
+    if (!ctx) return WRK_E_ARG;
+    LOCK(ctx);
+    WRK_ARG(ctx, !ctx->capturing, "capture already in progress");
+    WRK_HIP(ctx, hipSetDevice(ctx->device));
+    WRK_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    ctx->capturing = true;
+    return WRK_OK;
+}
+
+int32_t wrk_capture_end(wrk_ctx* ctx, wrk_program** out) {
+    if (!ctx || !out) return WRK_E_ARG;
+    LOCK(ctx);
+    *out = nullptr;
+    WRK_ARG(ctx, ctx->capturing, "no capture in progress");
+    ctx->capturing = false;
+    hipGraph_t g = nullptr;
+    WRK_HIP(ctx, hipStreamEndCapture(ctx->stream, &g));
+    hipGraphExec_t e = nullptr;
+    hipError_t err = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
+    if (err != hipSuccess) { hipGraphDestroy(g); return wrk_fail(ctx, WRK_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(err)); }
+    wrk_program* p = new wrk_program();
+    p->graph = g;
+    p->exec = e;
+    *out = p;
+    return WRK_OK;
+}
+
+int32_t wrk_program_launch(wrk_ctx* ctx, wrk_program* prog) {
+    if (!ctx || !prog) return WRK_E_ARG;
+    LOCK(ctx);
+    WRK_HIP(ctx, hipSetDevice(ctx->device));
+    WRK_HIP(ctx, hipGraphLaunch(prog->exec, ctx->stream));
+    return WRK_OK;
+}
+
+int32_t wrk_program_destroy(wrk_program* prog) {
+    if (!prog) return WRK_E_ARG;
+    if (prog->exec) hipGraphExecDestroy(prog->exec);
+    if (prog->graph) hipGraphDestroy(prog->graph);
+    delete prog;
+    return WRK_OK;
+}
+
+// ---------------------------------------------------------------- matrices
+static inline uint16_t f32_to_f16_bits(float f) {
+    _Float16 h = (_Float16)f;       // round-to-nearest-even, like half::f16::from_f32
+    uint16_t b;
+    memcpy(&b, &h, 2);
+    return b;
+}
+
+int32_t wrk_matrix_create(wrk_ctx* ctx, uint32_t kind, uint32_t k, uint32_t m, const void* data, size_t bytes, uint32_t flags,
+                          wrk_matrix** out) {
+    if (!ctx || !out || !data) return WRK_E_ARG;
+    LOCK(ctx);
+    *out = nullptr;
+    WRK_ARG(ctx, k > 0 && m > 0, "matrix dims must be positive");
+    uint32_t dev_kind = kind;
+    size_t expect = 0;
+    switch (kind) {
+        case WRK_MAT_F32: expect = (size_t)k * m * 4; dev_kind = WRK_MAT_F16; break;
+        case WRK_MAT_F16: expect = (size_t)k * m * 2; break;
+        case WRK_MAT_Q8_0:
+            WRK_ARG(ctx, k % 32 == 0, "Q8_0 needs K %% 32 == 0 (loader.rs:884-887)");
+            expect = (size_t)k / 32 * 34 * m;
+            break;
+        case WRK_MAT_Q4_K:
+        case WRK_MAT_Q5_K:
+        case WRK_MAT_Q6_K:
+            WRK_ARG(ctx, k % 256 == 0, "K-quants need K %% 256 == 0 (loader.rs:824-827)");
+            expect = wrk::stored_bytes(kind, k, m);
+            break;
+        default: return wrk_fail(ctx, WRK_E_UNSUPPORTED, "matrix kind %u not supported by wrk_matrix_create", kind);
+    }
+    WRK_ARG(ctx, bytes == expect, "matrix data is %zu bytes, expected %zu for kind %u [%u x %u]", bytes, expect, kind, k, m);
+    WRK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t rb = wrk::repack_row_bytes(dev_kind, k);
+    const size_t total = rb * m;
+    std::vector<uint8_t> host(total, 0);
+    if (kind == WRK_MAT_F32) {
+        std::vector<uint16_t> tmp((size_t)k * m);
+        const float* f = (const float*)data;
+#pragma omp parallel for schedule(static)
+        for (long long i = 0; i < (long long)tmp.size(); ++i) tmp[i] = f32_to_f16_bits(f[i]);
+        wrk::repack_rows(WRK_MAT_F16, k, m, (const uint8_t*)tmp.data(), host.data());
+    } else {
+        wrk::repack_rows(dev_kind, k, m, (const uint8_t*)data, host.data());
+    }
+    void* p = nullptr;
+    WRK_HIP(ctx, hipMalloc(&p, total + 256));
+    hipError_t e = hipMemcpyAsync(p, host.data(), total, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { hipFree(p); return wrk_fail(ctx, WRK_E_HIP, "matrix upload: %s", hipGetErrorString(e)); }
+    wrk_matrix* mt = new wrk_matrix{ctx, dev_kind, k, m, flags, (uint8_t*)p, rb, wrk::stored_bytes(kind, k, m), nullptr, 0, {1}};
+    *out = mt;
+    return WRK_OK;
+}
+
+int32_t wrk_matrix_quantize(wrk_ctx* ctx, uint32_t kind, uint32_t, uint32_t, const wrk_buf*, wrk_matrix** out) {
+    if (out) *out = nullptr;
+    return wrk_fail(ctx, WRK_E_UNSUPPORTED, "on-load Int8/NF4 quantisation (kind %u) is not built yet", kind);
+}
+
+int32_t wrk_matrix_release(wrk_matrix* mat) {
+    if (!mat) return WRK_E_ARG;
+    if (mat->refs.fetch_sub(1) == 1) {
+        wrk_ctx* ctx = mat->ctx;
+        LOCK(ctx);
+        hipSetDevice(ctx->device);
+        hipStreamSynchronize(ctx->stream);
+        hipFree(mat->data);
+        if (mat->aux) hipFree(mat->aux);
+        delete mat;
+    }
+    return WRK_OK;
+}
+
+size_t wrk_matrix_stream_bytes(const wrk_matrix* mat) { return mat ? mat->stored_bytes : 0; }
+
+// ---------------------------------------------------------------- op helpers
+static int32_t check_tensor(wrk_ctx* ctx, const wrk_tensor* t, const char* name) {
+    WRK_ARG(ctx, t && t->buf, "%s: null tensor", name);
+    WRK_ARG(ctx, t->dtype == WRK_F16 || t->dtype == WRK_F32, "%s: dtype must be f16 or f32", name);
+    const DTensor d = make_dtensor(t);
+    for (int i = 0; i < 3; ++i)
+        WRK_ARG(ctx, (size_t)d.offset[i] + d.shape[i] <= (size_t)(d.stride[i] ? d.stride[i] : 1) || d.shape[i] == 0,
+                "%s: view [%u..+%u) exceeds parent extent %u on axis %d", name, d.offset[i], d.shape[i], d.stride[i], i);
+    if (d.shape[0] && d.shape[1] && d.shape[2] && d.shape[3])
+        WRK_ARG(ctx, dtensor_extent(d) * dtype_size(t->dtype) <= t->buf->bytes, "%s: view exceeds its %zu-byte buffer", name, t->buf->bytes);
+    return WRK_OK;
+}
+#define CHECK_T(t, name)                                       \
+    do {                                                       \
+        int32_t _r = check_tensor(ctx, (t), (name));           \
+        if (_r != WRK_OK) return _r;                           \
+    } while (0)
+#define SAME_SHAPE(a, b) ((a)->view.shape[0] == (b)->view.shape[0] && (a)->view.shape[1] == (b)->view.shape[1] && (a)->view.shape[2] == (b)->view.shape[2])
+#define ENTER(ctx)                              \
+    if (!(ctx)) return WRK_E_ARG;               \
+    LOCK(ctx);                                  \
+    WRK_HIP(ctx, hipSetDevice((ctx)->device))
+
+int32_t wrk_op_matmul(wrk_ctx* ctx, const wrk_matrix* mat, const wrk_tensor* input, const wrk_tensor* output, uint32_t act,
+                      int32_t turbo, int32_t sparse) {
+    ENTER(ctx);
+    WRK_ARG(ctx, mat, "matmul: null matrix");
+    CHECK_T(input, "matmul input");
+    CHECK_T(output, "matmul output");
+    WRK_ARG(ctx, input->view.shape[0] == mat->k, "matmul: input has %u channels, matrix K = %u", input->view.shape[0], mat->k);
+    WRK_ARG(ctx, output->view.shape[0] == mat->m, "matmul: output has %u channels, matrix M = %u", output->view.shape[0], mat->m);
+    WRK_ARG(ctx, input->view.shape[1] == output->view.shape[1] && input->view.shape[2] == output->view.shape[2], "matmul: token/batch mismatch");
+    wrk::MatJob j{mat->data, mat->aux, mat->kind, mat->flags, mat->k, mat->m, (uint32_t)mat->row_bytes,
+                  make_dtensor(input), make_dtensor(output), act, (uint32_t)sparse};
+    int rc = -2;
+    if (turbo) rc = wrk::matmul_mfma(ctx->stream, j, ctx->num_cu);
+    if (rc == -2) rc = wrk::matvec(ctx->stream, &j, 1, ctx->num_cu);
+    WRK_ARG(ctx, rc == 0, "matmul: launch configuration rejected");
+    WRK_LAUNCH_CHECK(ctx);
+    return WRK_OK;
+}
+
+int32_t wrk_op_layer_norm(wrk_ctx* ctx, const wrk_buf* w, const wrk_buf* b, const wrk_tensor* x, float eps) {
+    ENTER(ctx);
+    CHECK_T(x, "layer_norm x");
+    WRK_ARG(ctx, w && b && w->bytes >= (size_t)x->view.shape[0] * 2 && b->bytes >= (size_t)x->view.shape[0] * 2, "layer_norm: w/b must hold C f16");
+    wrk::layer_norm(ctx->stream, w->ptr, b->ptr, make_dtensor(x), eps);
+    WRK_LAUNCH_CHECK(ctx);
+    return WRK_OK;
+}
+
+int32_t wrk_op_group_norm(wrk_ctx* ctx, const wrk_buf* w, const wrk_buf* b, const wrk_tensor* x, float eps) {
+    ENTER(ctx);
+    CHECK_T(x, "group_norm x");
+    const size_t need = (size_t)x->view.shape[0] * x->view.shape[1] * 2;
+    WRK_ARG(ctx, w && b && w->bytes >= need && b->bytes >= need, "group_norm: w/b must hold S*H f16");
+    WRK_ARG(ctx, x->view.shape[0] <= 64 * 1024, "group_norm: head size too large");
+    wrk::group_norm(ctx->stream, w->ptr, b->ptr, make_dtensor(x), eps);
+    WRK_LAUNCH_CHECK(ctx);
+    return WRK_OK;
+}
+
+int32_t wrk_op_l2_norm(wrk_ctx* ctx, const wrk_tensor* x, float eps) {
+    ENTER(ctx);
+    CHECK_T(x, "l2_norm x");
+    wrk::l2_norm(ctx->stream, make_dtensor(x), eps);
+    WRK_LAUNCH_CHECK(ctx);
+    return WRK_OK;
+}
+
+int32_t wrk_op_token_shift(wrk_ctx* ctx, const wrk_buf* cursors, const wrk_buf* time_mix, const wrk_tensor* state,
+                           const wrk_tensor* input, const wrk_tensor* output, int32_t reversed) {
+    ENTER(ctx);
+    CHECK_T(state, "token_shift state");
+    CHECK_T(input, "token_shift input");
+    CHECK_T(output, "token_shift output");
+    WRK_ARG(ctx, SAME_SHAPE(input, output), "token_shift: input/output shape mismatch");
+    WRK_ARG(ctx, input->view.shape[2] == 1, "token_shift: input must be [C, T, 1]");
+    WRK_ARG(ctx, state->view.shape[0] == input->view.shape[0] && state->view.shape[1] == 1, "token_shift: state must be [C, 1, B]");
+    WRK_ARG(ctx, cursors && cursors->bytes >= (size_t)input->view.shape[1] * 4, "token_shift: cursors must hold T u32");
+    WRK_ARG(ctx, time_mix && time_mix->bytes >= (size_t)input->view.shape[0] * 2, "token_shift: time_mix must hold C f16");
+    wrk::token_shift(ctx->stream, (const uint32_t*)cursors->ptr, time_mix->ptr, make_dtensor(state), make_dtensor(input), make_dtensor(output), reversed);
+    WRK_LAUNCH_CHECK(ctx);
+    return WRK_OK;
+}
+
+static int32_t binary_op(wrk_ctx* ctx, int is_mul, const wrk_tensor* input, const wrk_tensor* output, uint32_t ax, uint32_t ay, uint32_t ao) {
+    ENTER(ctx);
+    CHECK_T(input, "binary input");
+    CHECK_T(output, "binary output");
+    WRK_ARG(ctx, input->view.shape[0] == output->view.shape[0], "binary: channel mismatch");
+    WRK_ARG(ctx, input->view.shape[1] == 1 || input->view.shape[1] == output->view.shape[1], "binary: token extent must be 1 or equal");
+    WRK_ARG(ctx, input->view.shape[2] == 1 || input->view.shape[2] == output->view.shape[2], "binary: batch extent must be 1 or equal");
+    wrk::binary(ctx->stream, is_mul, make_dtensor(input), make_dtensor(output), ax, ay, ao);
+    WRK_LAUNCH_CHECK(ctx);
+    return WRK_OK;
+}
+int32_t wrk_op_add(wrk_ctx* ctx, const wrk_tensor* i, const wrk_tensor* o, uint32_t ax, uint32_t ay, uint32_t ao) { return binary_op(ctx, 0, i, o, ax, ay, ao); }
+int32_t wrk_op_mul(wrk_ctx* ctx, const wrk_tensor* i, const wrk_tensor* o, uint32_t ax, uint32_t ay, uint32_t ao) { return binary_op(ctx, 1, i, o, ax, ay, ao); }
+
+int32_t wrk_op_lerp(wrk_ctx* ctx, const wrk_tensor* x, const wrk_tensor* y, const wrk_tensor* f, int32_t reversed) {
+    ENTER(ctx);
+    CHECK_T(x, "lerp x");
+    CHECK_T(y, "lerp y");
+    CHECK_T(f, "lerp f");
+    WRK_ARG(ctx, SAME_SHAPE(x, y), "lerp: x/y shape mismatch");
+    WRK_ARG(ctx, f->view.shape[0] == y->view.shape[0], "lerp: factor channel mismatch");
+    wrk::lerp(ctx->stream, make_dtensor(x), make_dtensor(y), make_dtensor(f), reversed);
+    WRK_LAUNCH_CHECK(ctx);
+    return WRK_OK;
+}
+
+int32_t wrk_op_blit(wrk_ctx* ctx, const wrk_tensor* input, const wrk_tensor* output) {
+    ENTER(ctx);
+    CHECK_T(input, "blit input");
+    CHECK_T(output, "blit output");
+    WRK_ARG(ctx, SAME_SHAPE(input, output), "blit: shape mismatch");
+    wrk::blit(ctx->stream, make_dtensor(input), make_dtensor(output));
+    WRK_LAUNCH_CHECK(ctx);
+    return WRK_OK;
+}
+
+int32_t wrk_op_affine(wrk_ctx* ctx, const wrk_tensor* x, float scale, float bias) {
+    ENTER(ctx);
+    CHECK_T(x, "affine x");
+    wrk::affine(ctx->stream, make_dtensor(x), scale, bias);
+    WRK_LAUNCH_CHECK(ctx);
+    return WRK_OK;
+}
+
+int32_t wrk_op_activate(wrk_ctx* ctx, const wrk_tensor* x, uint32_t act) {
+    ENTER(ctx);
+    CHECK_T(x, "activate x");
+    wrk::activate(ctx->stream, make_dtensor(x), act);
+    WRK_LAUNCH_CHECK(ctx);
+    return WRK_OK;
+}
+
+int32_t wrk_op_control_k_v7(wrk_ctx* ctx, const wrk_buf* p, const wrk_tensor* a, const wrk_tensor* k) {
+    ENTER(ctx);
+    CHECK_T(a, "control_k a");
+    CHECK_T(k, "control_k k");
+    WRK_ARG(ctx, SAME_SHAPE(a, k), "control_k: a/k shape mismatch");
+    WRK_ARG(ctx, p && p->bytes >= (size_t)k->view.shape[0] * 2, "control_k: p must hold C f16");
+    wrk::control_k_v7(ctx->stream, p->ptr, make_dtensor(a), make_dtensor(k));
+    WRK_LAUNCH_CHECK(ctx);
+    return WRK_OK;
+}
+
+int32_t wrk_op_time_mix_v7(wrk_ctx* ctx, const wrk_buf* cursors, const wrk_tensor* state, const wrk_tensor* r, const wrk_tensor* w,
+                           const wrk_tensor* n, const wrk_tensor* x) {
+    ENTER(ctx);
+    CHECK_T(state, "time_mix state");
+    CHECK_T(r, "time_mix r");
+    CHECK_T(w, "time_mix w");
+    CHECK_T(n, "time_mix n");
+    CHECK_T(x, "time_mix x");
+    const uint32_t S = r->view.shape[0], H = r->view.shape[1], T = r->view.shape[2];
+    WRK_ARG(ctx, S == 64, "time_mix_v7: head size %u unsupported (64 only, as every RWKV-7 World model)", S);
+    WRK_ARG(ctx, SAME_SHAPE(r, w) && SAME_SHAPE(r, x), "time_mix_v7: r/w/x shape mismatch");
+    WRK_ARG(ctx, n->view.shape[0] == S && n->view.shape[1] == H && n->view.shape[2] == T && n->view.shape[3] == 4, "time_mix_v7: n must be [S, H, T, 4]");
+    WRK_ARG(ctx, state->view.shape[0] == S * H && state->view.shape[1] == S + 1, "time_mix_v7: state must be [C, S+1, B]");
+    WRK_ARG(ctx, state->dtype == WRK_F32, "time_mix_v7: state must be f32");
+    WRK_ARG(ctx, cursors && cursors->bytes >= (size_t)T * 4, "time_mix_v7: cursors must hold T u32");
+    wrk::time_mix_v7(ctx->stream, (const uint32_t*)cursors->ptr, make_dtensor(state), make_dtensor(r), make_dtensor(w), make_dtensor(n), make_dtensor(x));
+    WRK_LAUNCH_CHECK(ctx);
+    return WRK_OK;
+}
+
+int32_t wrk_op_time_first_v7(wrk_ctx* ctx, const wrk_buf* u, const wrk_tensor* r, const wrk_tensor* n, const wrk_tensor* x) {
+    ENTER(ctx);
+    CHECK_T(r, "time_first r");
+    CHECK_T(n, "time_first n");
+    CHECK_T(x, "time_first x");
+    WRK_ARG(ctx, r->view.shape[0] == 64, "time_first_v7: head size must be 64");
+    WRK_ARG(ctx, SAME_SHAPE(r, x), "time_first_v7: r/x shape mismatch");
+    WRK_ARG(ctx, u && u->bytes >= (size_t)r->view.shape[0] * r->view.shape[1] * 2, "time_first_v7: u must hold S*H f16");
+    wrk::time_first_v7(ctx->stream, u->ptr, make_dtensor(r), make_dtensor(n), make_dtensor(x));
+    WRK_LAUNCH_CHECK(ctx);
+    return WRK_OK;
+}
+
+int32_t wrk_op_channel_mix_v7(wrk_ctx* ctx, const wrk_buf* cursors, const wrk_tensor* state, const wrk_tensor* v, const wrk_tensor* x) {
+    ENTER(ctx);
+    CHECK_T(state, "channel_mix state");
+    CHECK_T(v, "channel_mix v");
+    CHECK_T(x, "channel_mix x");
+    WRK_ARG(ctx, SAME_SHAPE(v, x), "channel_mix: v/x shape mismatch");
+    WRK_ARG(ctx, state->view.shape[0] == x->view.shape[0] && state->view.shape[1] == 1, "channel_mix: state must be [C, 1, B]");
+    WRK_ARG(ctx, cursors && cursors->bytes >= (size_t)x->view.shape[1] * 4, "channel_mix: cursors must hold T u32");
+    wrk::channel_mix_v7(ctx->stream, (const uint32_t*)cursors->ptr, make_dtensor(state), make_dtensor(v), make_dtensor(x));
+    WRK_LAUNCH_CHECK(ctx);
+    return WRK_OK;
+}
+
+int32_t wrk_op_softmax(wrk_ctx* ctx, const wrk_tensor* x) {
+    ENTER(ctx);
+    CHECK_T(x, "softmax x");
+    wrk::softmax(ctx->stream, make_dtensor(x));
+    WRK_LAUNCH_CHECK(ctx);
+    return WRK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,85 @@
+// Device-side helpers shared by all gfx950 kernels: f16 storage, View addressing, activations,
+// wave64 / workgroup reductions.  Compiled with -ffp-contract=off: every fused multiply-add is
+// written explicitly so rounding follows the reference's expressions.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "wrk_internal.h"
+
+typedef _Float16 f16;
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define WAVE 64
+
+// ------------------------------------------------------------------ rounding points
+// Round an f32 to the f16 the reference would have stored in a Runtime<f16> buffer.
+__device__ __forceinline__ float r16(float x) { return (float)(f16)x; }
+
+// ------------------------------------------------------------------ View addressing
+__device__ __forceinline__ size_t dt_index(const DTensor& d, uint32_t c, uint32_t t, uint32_t b) {
+    return ((size_t)(b + d.offset[2]) * d.stride[1] + (t + d.offset[1])) * d.stride[0] + c + d.offset[0];
+}
+__device__ __forceinline__ size_t dt_index4(const DTensor& d, uint32_t c, uint32_t t, uint32_t b, uint32_t w) {
+    return (((size_t)(w + d.offset[3]) * d.stride[2] + (b + d.offset[2])) * d.stride[1] + (t + d.offset[1])) * d.stride[0] + c + d.offset[0];
+}
+__device__ __forceinline__ float dt_load(const DTensor& d, size_t i) {
+    return d.dtype == WRK_F16 ? (float)((const f16*)d.p)[i] : ((const float*)d.p)[i];
+}
+__device__ __forceinline__ void dt_store(const DTensor& d, size_t i, float v) {
+    if (d.dtype == WRK_F16) ((f16*)d.p)[i] = (f16)v; else ((float*)d.p)[i] = v;
+}
+// value as it reads back from the buffer after a store (f16 buffers round)
+__device__ __forceinline__ float dt_round(const DTensor& d, float v) { return d.dtype == WRK_F16 ? r16(v) : v; }
+
+// ------------------------------------------------------------------ cursors (tensor/mod.rs:53-60)
+struct Cursor { uint32_t batch, token, len; };
+__device__ __forceinline__ Cursor unpack_cursor(uint32_t x) {
+    Cursor c; c.batch = x & 0xffu; c.token = (x >> 8) & 0xffffu; c.len = (x >> 24) & 0xffu; return c;
+}
+
+// ------------------------------------------------------------------ activations (ops.rs:205-235)
+__device__ __forceinline__ float act_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float act_apply(uint32_t act, float x) {
+    switch (act) {
+        case WRK_ACT_SQUARED_RELU: { float p = fmaxf(x, 0.0f); return p * p; }
+        case WRK_ACT_TANH: return x > 42.0f ? 1.0f : tanhf(x);
+        case WRK_ACT_STABLE_EXP: return __expf(-__expf(x));
+        case WRK_ACT_OPPOSITE_EXP: return -__expf(x);
+        case WRK_ACT_SOFTPLUS: return __logf(1.0f + __expf(x));
+        case WRK_ACT_SIGMOID: return act_sigmoid(x);
+        case WRK_ACT_SILU: return x / (1.0f + __expf(-x));
+        default: return x;
+    }
+}
+// WGSL mix(x, y, a) = x * (1 - a) + y * a
+__device__ __forceinline__ float wgsl_mix(float x, float y, float a) { return x * (1.0f - a) + y * a; }
+
+// ------------------------------------------------------------------ reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, WAVE));
+    return v;
+}
+// sum over a workgroup of NW waves; `red` is NW floats of LDS; result broadcast to all threads
+template <int NW>
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float t = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) t += red[i];
+    return t;
+}

@@ -1,0 +1,163 @@
+// Internal host-side structures behind the opaque handles of include/wrk_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "wrk_hip.h"
+
+struct wrk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;       // submission stream (ops, programs)
+    hipStream_t read_stream = nullptr;  // read-back stream (context.rs:148-162 readback thread)
+    hipEvent_t read_event = nullptr;
+    std::recursive_mutex mu;
+    std::string err;
+    bool capturing = false;
+    int num_cu = 256;
+    void* staging = nullptr;            // pinned host staging for wrk_buf_write
+    size_t staging_bytes = 0;
+};
+
+struct wrk_buf {
+    wrk_ctx* ctx;
+    void* ptr;
+    size_t bytes;
+    std::atomic<int> refs;
+};
+
+struct wrk_matrix {
+    wrk_ctx* ctx;
+    uint32_t kind, k, m, flags;
+    uint8_t* data;          // re-laid-out weight stream (device)
+    size_t row_bytes;       // device bytes per row (16-byte aligned)
+    size_t stored_bytes;    // algorithmic bytes = GGUF/f16 stored size of the tensor
+    // INT8 / NF4 side tables (web-rwkv formats)
+    uint8_t* aux = nullptr;     // int8: (min,max) f16 per 128 elements; nf4: absmax f16 per 64 elements
+    size_t aux_bytes = 0;
+    std::atomic<int> refs;
+};
+
+struct wrk_program {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
+inline int32_t wrk_fail(wrk_ctx* ctx, int32_t code, const char* fmt, ...) __attribute__((format(printf, 3, 4)));
+inline int32_t wrk_fail(wrk_ctx* ctx, int32_t code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+#define WRK_HIP(ctx, expr)                                                                              \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess)                                                                           \
+            return wrk_fail((ctx), _e == hipErrorOutOfMemory ? WRK_E_OOM : WRK_E_HIP, "%s: %s (%s:%d)", \
+                            #expr, hipGetErrorString(_e), __FILE__, __LINE__);                          \
+    } while (0)
+
+#define WRK_ARG(ctx, cond, ...)                                     \
+    do {                                                            \
+        if (!(cond)) return wrk_fail((ctx), WRK_E_ARG, __VA_ARGS__); \
+    } while (0)
+
+#define WRK_LAUNCH_CHECK(ctx) WRK_HIP(ctx, hipGetLastError())
+
+// ------------------------------------------------------------------ device-side tensor descriptor
+// Mirrors `View` addressing (see wrk_hip.h).  Passed by value to kernels.
+struct DTensor {
+    void* p;
+    uint32_t dtype;     // WRK_F16 / WRK_F32
+    uint32_t shape[4];
+    uint32_t stride[4];
+    uint32_t offset[4];
+};
+
+inline DTensor make_dtensor(const wrk_tensor* t) {
+    DTensor d;
+    d.p = t->buf ? t->buf->ptr : nullptr;
+    d.dtype = t->dtype;
+    for (int i = 0; i < 4; ++i) {
+        d.shape[i] = t->view.shape[i];
+        d.stride[i] = t->view.stride[i];
+        d.offset[i] = t->view.offset[i];
+    }
+    return d;
+}
+
+inline DTensor make_dense(void* p, uint32_t dtype, uint32_t c, uint32_t t = 1, uint32_t b = 1, uint32_t w = 1) {
+    DTensor d;
+    d.p = p;
+    d.dtype = dtype;
+    d.shape[0] = c; d.shape[1] = t; d.shape[2] = b; d.shape[3] = w;
+    d.stride[0] = c; d.stride[1] = t; d.stride[2] = b; d.stride[3] = w;
+    d.offset[0] = d.offset[1] = d.offset[2] = d.offset[3] = 0;
+    return d;
+}
+
+inline size_t dtype_size(uint32_t dt) { return dt == WRK_F16 ? 2 : (dt == WRK_U8 ? 1 : 4); }
+
+// number of elements the view's parent tensor must hold for the view to be in bounds
+inline size_t dtensor_extent(const DTensor& d) {
+    size_t s0 = d.stride[0], s1 = d.stride[1], s2 = d.stride[2] ? d.stride[2] : 1;
+    size_t last_w = (size_t)d.offset[3] + (d.shape[3] ? d.shape[3] - 1 : 0);
+    size_t last_b = (size_t)d.offset[2] + (d.shape[2] ? d.shape[2] - 1 : 0);
+    size_t last_t = (size_t)d.offset[1] + (d.shape[1] ? d.shape[1] - 1 : 0);
+    size_t last_c = (size_t)d.offset[0] + (d.shape[0] ? d.shape[0] - 1 : 0);
+    return ((last_w * s2 + last_b) * s1 + last_t) * s0 + last_c + 1;
+}
+
+// ------------------------------------------------------------------ internal launchers (stream ordered)
+namespace wrk {
+
+// wrk_ops.hip
+void layer_norm(hipStream_t s, const void* w, const void* b, DTensor x, float eps);
+void group_norm(hipStream_t s, const void* w, const void* b, DTensor x, float eps);
+void l2_norm(hipStream_t s, DTensor x, float eps);
+void token_shift(hipStream_t s, const uint32_t* cursors, const void* mix, DTensor state, DTensor in, DTensor out, int reversed);
+void binary(hipStream_t s, int is_mul, DTensor in, DTensor out, uint32_t ax, uint32_t ay, uint32_t ao);
+void lerp(hipStream_t s, DTensor x, DTensor y, DTensor f, int reversed);
+void blit(hipStream_t s, DTensor in, DTensor out);
+void affine(hipStream_t s, DTensor x, float scale, float bias);
+void activate(hipStream_t s, DTensor x, uint32_t act);
+void control_k_v7(hipStream_t s, const void* p, DTensor a, DTensor k);
+void time_mix_v7(hipStream_t s, const uint32_t* cursors, DTensor state, DTensor r, DTensor w, DTensor n, DTensor x);
+void time_first_v7(hipStream_t s, const void* u, DTensor r, DTensor n, DTensor x);
+void channel_mix_v7(hipStream_t s, const uint32_t* cursors, DTensor state, DTensor v, DTensor x);
+void softmax(hipStream_t s, DTensor x);
+void gather_rows_f16(hipStream_t s, const void* table, const uint32_t* ids, void* out, uint32_t d, uint32_t n);
+void gather_rows_any(hipStream_t s, DTensor in, const uint32_t* rows, DTensor out, uint32_t n);
+void argmax_rows(hipStream_t s, const float* logits, uint32_t v, uint32_t v_stride, uint32_t n, uint32_t* out);
+
+// wrk_matvec.hip
+struct MatJob {
+    const uint8_t* w;       // matrix data (device layout)
+    const uint8_t* aux;
+    uint32_t kind, flags;
+    uint32_t k, m;
+    uint32_t row_bytes;
+    DTensor in;             // [K, T, B]
+    DTensor out;            // [M, T, B]
+    uint32_t act;
+    uint32_t sparse;
+};
+int matvec(hipStream_t s, const MatJob* jobs, int njobs, int num_cu);
+int matmul_mfma(hipStream_t s, const MatJob& job, int num_cu);
+size_t repack_row_bytes(uint32_t kind, uint32_t k);
+int repack_rows(uint32_t kind, uint32_t k, uint32_t m, const uint8_t* src, uint8_t* dst);   // host side
+size_t stored_bytes(uint32_t kind, uint32_t k, uint32_t m);
+
+}  // namespace wrk

@@ -1,0 +1,371 @@
+// Op-by-op kernels: one kernel per reference TensorOp on the V7/V6 path.
+// These are the "mode 0" path of wrk_v7_infer, the prefill path's elementwise layer, and the
+// kernels behind the wrk_op_* entry points.  The decode fast path fuses them (wrk_v7_fused.hip).
+//
+// All arithmetic is f32; loads/stores convert to the buffer dtype (f16 for Runtime<f16> buffers,
+// f32 for state / logits), which reproduces the reference's rounding points.
+#include "wrk_device.h"
+
+namespace wrk {
+
+// ------------------------------------------------------------------ layer_norm / group_norm
+// shaders/layer_norm.wgsl:63-121.  One workgroup per row; statistics two-pass in f32
+// (mean, then centred second moment: same quantities as the shader's Welford merge).
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK) layer_norm_kernel(const f16* __restrict__ w, const f16* __restrict__ b, DTensor x,
+                                                            float eps, int group) {
+    __shared__ float red[BLOCK / 64];
+    const uint32_t C = x.shape[0];
+    const uint32_t token = blockIdx.x, batch = blockIdx.y;
+    const size_t base = dt_index(x, 0, token, batch);
+    const uint32_t wofs = group ? token * C : 0;    // GROUP_NORM: h = token * stride
+    float s = 0.0f;
+    for (uint32_t i = threadIdx.x; i < C; i += BLOCK) s += dt_load(x, base + i);
+    const float mean = block_sum<BLOCK / 64>(s, red) / (float)C;
+    float q = 0.0f;
+    for (uint32_t i = threadIdx.x; i < C; i += BLOCK) { float d = dt_load(x, base + i) - mean; q += d * d; }
+    const float var = block_sum<BLOCK / 64>(q, red) / (float)C + eps;
+    const float dev = 1.0f / sqrtf(var);
+    for (uint32_t i = threadIdx.x; i < C; i += BLOCK) {
+        float value = (dt_load(x, base + i) - mean) * dev;
+        dt_store(x, base + i, __builtin_fmaf(value, (float)w[wofs + i], (float)b[wofs + i]));
+    }
+}
+
+void layer_norm(hipStream_t s, const void* w, const void* b, DTensor x, float eps) {
+    dim3 grid(x.shape[1], x.shape[2]);
+    if (grid.x == 0 || grid.y == 0) return;
+    layer_norm_kernel<256><<<grid, 256, 0, s>>>((const f16*)w, (const f16*)b, x, eps, 0);
+}
+
+void group_norm(hipStream_t s, const void* w, const void* b, DTensor x, float eps) {
+    // x [S, H, T]: "token" = head, "batch" = token (ops.rs:460-508)
+    dim3 grid(x.shape[1], x.shape[2]);
+    if (grid.x == 0 || grid.y == 0) return;
+    layer_norm_kernel<64><<<grid, 64, 0, s>>>((const f16*)w, (const f16*)b, x, eps, 1);
+}
+
+// ------------------------------------------------------------------ l2_norm (normalize.wgsl:117-152)
+__global__ void __launch_bounds__(64) l2_norm_kernel(DTensor x, float eps) {
+    const uint32_t C = x.shape[0];
+    const size_t base = dt_index(x, 0, blockIdx.x, blockIdx.y);
+    float s = 0.0f;
+    for (uint32_t i = threadIdx.x; i < C; i += 64) { float v = dt_load(x, base + i); s += v * v; }
+    s = wave_sum(s);
+    const float norm = 1.0f / sqrtf(s + eps);
+    for (uint32_t i = threadIdx.x; i < C; i += 64) dt_store(x, base + i, dt_load(x, base + i) * norm);
+}
+
+void l2_norm(hipStream_t s, DTensor x, float eps) {
+    dim3 grid(x.shape[1], x.shape[2]);
+    if (grid.x == 0 || grid.y == 0) return;
+    l2_norm_kernel<<<grid, 64, 0, s>>>(x, eps);
+}
+
+// ------------------------------------------------------------------ token_shift (token_shift.wgsl:85-117)
+__global__ void __launch_bounds__(256) token_shift_kernel(const uint32_t* __restrict__ cursors, const f16* __restrict__ mixw,
+                                                           DTensor st, DTensor in, DTensor out, int reversed) {
+    const uint32_t C = in.shape[0];
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t stack = blockIdx.y;
+    if (c >= C) return;
+    const Cursor cur = unpack_cursor(cursors[stack]);
+    const float f = (float)mixw[c];
+    const float xt = dt_load(in, dt_index(in, c, stack, 0));
+    const float prev = (stack == cur.token) ? dt_load(st, dt_index(st, c, 0, cur.batch))
+                                            : dt_load(in, dt_index(in, c, stack - 1, 0));
+    const float v = reversed ? wgsl_mix(xt, prev, f) : wgsl_mix(prev, xt, f);
+    dt_store(out, dt_index(out, c, stack, 0), v);
+}
+
+void token_shift(hipStream_t s, const uint32_t* cursors, const void* mixw, DTensor st, DTensor in, DTensor out, int reversed) {
+    if (in.shape[1] == 0) return;
+    dim3 grid((in.shape[0] + 255) / 256, in.shape[1]);
+    token_shift_kernel<<<grid, 256, 0, s>>>(cursors, (const f16*)mixw, st, in, out, reversed);
+}
+
+// ------------------------------------------------------------------ add / mul (binary.wgsl:38-78)
+__global__ void __launch_bounds__(256) binary_kernel(int is_mul, DTensor in, DTensor out, uint32_t ax, uint32_t ay, uint32_t ao) {
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t t = blockIdx.y, b = blockIdx.z;
+    if (c >= out.shape[0]) return;
+    const float x = dt_load(in, dt_index(in, c, in.shape[1] == 1 ? 0 : t, in.shape[2] == 1 ? 0 : b));
+    const size_t o = dt_index(out, c, t, b);
+    const float y = dt_load(out, o);
+    const float xv = act_apply(ax, x), yv = act_apply(ay, y);
+    dt_store(out, o, act_apply(ao, is_mul ? xv * yv : xv + yv));
+}
+
+void binary(hipStream_t s, int is_mul, DTensor in, DTensor out, uint32_t ax, uint32_t ay, uint32_t ao) {
+    if (out.shape[1] == 0 || out.shape[2] == 0) return;
+    dim3 grid((out.shape[0] + 255) / 256, out.shape[1], out.shape[2]);
+    binary_kernel<<<grid, 256, 0, s>>>(is_mul, in, out, ax, ay, ao);
+}
+
+// ------------------------------------------------------------------ lerp (lerp.wgsl:74-92)
+__global__ void __launch_bounds__(256) lerp_kernel(DTensor x, DTensor y, DTensor f, int reversed) {
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t t = blockIdx.y, b = blockIdx.z;
+    if (c >= y.shape[0]) return;
+    const float fv = dt_load(f, dt_index(f, c, f.shape[1] == 1 ? 0 : t, f.shape[2] == 1 ? 0 : b));
+    const float xv = dt_load(x, dt_index(x, c, t, b));
+    const size_t o = dt_index(y, c, t, b);
+    const float yv = dt_load(y, o);
+    dt_store(y, o, reversed ? wgsl_mix(yv, xv, fv) : wgsl_mix(xv, yv, fv));
+}
+
+void lerp(hipStream_t s, DTensor x, DTensor y, DTensor f, int reversed) {
+    if (y.shape[1] == 0 || y.shape[2] == 0) return;
+    dim3 grid((y.shape[0] + 255) / 256, y.shape[1], y.shape[2]);
+    lerp_kernel<<<grid, 256, 0, s>>>(x, y, f, reversed);
+}
+
+// ------------------------------------------------------------------ blit / affine / activate
+__global__ void __launch_bounds__(256) blit_kernel(DTensor in, DTensor out) {
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t t = blockIdx.y, b = blockIdx.z;
+    if (c >= out.shape[0]) return;
+    dt_store(out, dt_index(out, c, t, b), dt_load(in, dt_index(in, c, t, b)));
+}
+
+void blit(hipStream_t s, DTensor in, DTensor out) {
+    if (out.shape[1] == 0 || out.shape[2] == 0) return;
+    dim3 grid((out.shape[0] + 255) / 256, out.shape[1], out.shape[2]);
+    blit_kernel<<<grid, 256, 0, s>>>(in, out);
+}
+
+__global__ void __launch_bounds__(256) affine_kernel(DTensor x, float scale, float bias, uint32_t act, int do_affine) {
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= x.shape[0]) return;
+    const size_t o = dt_index(x, c, blockIdx.y, blockIdx.z);
+    float v = dt_load(x, o);
+    v = do_affine ? __builtin_fmaf(scale, v, bias) : act_apply(act, v);
+    dt_store(x, o, v);
+}
+
+void affine(hipStream_t s, DTensor x, float scale, float bias) {
+    if (x.shape[1] == 0 || x.shape[2] == 0) return;
+    dim3 grid((x.shape[0] + 255) / 256, x.shape[1], x.shape[2]);
+    affine_kernel<<<grid, 256, 0, s>>>(x, scale, bias, 0, 1);
+}
+
+void activate(hipStream_t s, DTensor x, uint32_t act) {
+    if (x.shape[1] == 0 || x.shape[2] == 0) return;
+    dim3 grid((x.shape[0] + 255) / 256, x.shape[1], x.shape[2]);
+    affine_kernel<<<grid, 256, 0, s>>>(x, 0.f, 0.f, act, 0);
+}
+
+// ------------------------------------------------------------------ control_k_v7 (control_k_v7.wgsl:60-75)
+__global__ void __launch_bounds__(256) control_k_kernel(const f16* __restrict__ p, DTensor a, DTensor k) {
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= k.shape[0]) return;
+    const float pv = (float)p[c];
+    const float av = dt_load(a, dt_index(a, c, blockIdx.y, blockIdx.z));
+    const size_t o = dt_index(k, c, blockIdx.y, blockIdx.z);
+    const float kv = dt_load(k, o);
+    dt_store(k, o, kv * (1.0f + (av - 1.0f) * pv));
+}
+
+void control_k_v7(hipStream_t s, const void* p, DTensor a, DTensor k) {
+    if (k.shape[1] == 0 || k.shape[2] == 0) return;
+    dim3 grid((k.shape[0] + 255) / 256, k.shape[1], k.shape[2]);
+    control_k_kernel<<<grid, 256, 0, s>>>((const f16*)p, a, k);
+}
+
+// ------------------------------------------------------------------ time_mix_v7 (time_mix_v7.wgsl:143-221)
+// One workgroup per (head, sequence-chunk).  The 64x64 f32 state of the head lives in registers for
+// the whole chunk: thread (i = tid & 63, g = tid >> 6) owns S[16g .. 16g+15][i].  grid = (H, T):
+// the workgroup whose stacked token index is the first of a sequence runs that sequence, the others
+// exit, so sequences of one dispatch run concurrently (the reference serialises them).
+//   w~ = exp(-0.606531 * sigmoid(w));  a~ = -kk;  b~ = kk * a
+//   sa[i]  = sum_j S[j,i] * a~[j]
+//   S[j,i] = S[j,i] * w~[j] + k[j] * v[i] + sa[i] * b~[j]
+//   y[i]   = sum_j r[j] * S[j,i]
+// r, w, x are [S, H, T]; n is [S, H, T, 4] = (k, v, a, kk); state view [C, S+1, B] rows: 0 = shift.
+__global__ void __launch_bounds__(256) time_mix_v7_kernel(const uint32_t* __restrict__ cursors, DTensor st, DTensor r, DTensor w,
+                                                           DTensor n, DTensor x) {
+    constexpr int S = 64;
+    __shared__ float sh_r[S], sh_w[S], sh_k[S], sh_a[S], sh_b[S];
+    __shared__ float sh_red[4][S];
+    const uint32_t head = blockIdx.x, t0 = blockIdx.y;
+    const Cursor cur = unpack_cursor(cursors[t0]);
+    if (cur.token != t0) return;                     // not the first token of a sequence chunk
+    const uint32_t tid = threadIdx.x, i = tid & 63, g = tid >> 6;
+    const uint32_t ch = head * S + i;                // channel of this thread's value column
+
+    // token-shift carry: state row 0 <- att_x of the sequence's last token (read before it is overwritten)
+    if (g == 0) {
+        const uint32_t last = cur.token + cur.len - 1;
+        dt_store(st, dt_index(st, ch, 0, cur.batch), dt_load(x, dt_index(x, i, head, last)));
+    }
+    float Sreg[16];
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) Sreg[jj] = dt_load(st, dt_index(st, ch, 1 + g * 16 + jj, cur.batch));
+
+    for (uint32_t t = cur.token; t < cur.token + cur.len; ++t) {
+        __syncthreads();
+        if (g == 0) {
+            sh_r[i] = dt_load(r, dt_index(r, i, head, t));
+            sh_w[i] = __expf(-0.606531f * act_sigmoid(dt_load(w, dt_index(w, i, head, t))));
+            sh_k[i] = dt_load(n, dt_index4(n, i, head, t, 0));
+            const float a = dt_load(n, dt_index4(n, i, head, t, 2));
+            const float kk = dt_load(n, dt_index4(n, i, head, t, 3));
+            sh_a[i] = -kk;
+            sh_b[i] = kk * a;
+        }
+        __syncthreads();
+        float sa = 0.0f;
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) sa = __builtin_fmaf(Sreg[jj], sh_a[g * 16 + jj], sa);
+        sh_red[g][i] = sa;
+        __syncthreads();
+        sa = (sh_red[0][i] + sh_red[1][i]) + (sh_red[2][i] + sh_red[3][i]);
+        const float vv = dt_load(n, dt_index4(n, i, head, t, 1));
+        float y = 0.0f;
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) {
+            const int j = g * 16 + jj;
+            const float s = Sreg[jj] * sh_w[j] + sh_k[j] * vv + sa * sh_b[j];
+            Sreg[jj] = s;
+            y = __builtin_fmaf(sh_r[j], s, y);
+        }
+        __syncthreads();
+        sh_red[g][i] = y;
+        __syncthreads();
+        if (g == 0) {
+            y = (sh_red[0][i] + sh_red[1][i]) + (sh_red[2][i] + sh_red[3][i]);
+            dt_store(x, dt_index(x, i, head, t), y);
+        }
+    }
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) dt_store(st, dt_index(st, ch, 1 + g * 16 + jj, cur.batch), Sreg[jj]);
+}
+
+void time_mix_v7(hipStream_t s, const uint32_t* cursors, DTensor st, DTensor r, DTensor w, DTensor n, DTensor x) {
+    if (r.shape[2] == 0) return;
+    dim3 grid(r.shape[1], r.shape[2]);
+    time_mix_v7_kernel<<<grid, 256, 0, s>>>(cursors, st, r, w, n, x);
+}
+
+// ------------------------------------------------------------------ time_first_v7 (time_mix_v7.wgsl:223-262)
+// x[i] += (sum_j u[j] * k[j] * r[j]) * v[i] per head; one wave per (head, token)
+__global__ void __launch_bounds__(64) time_first_v7_kernel(const f16* __restrict__ u, DTensor r, DTensor n, DTensor x) {
+    const uint32_t head = blockIdx.x, t = blockIdx.y, i = threadIdx.x;
+    const float uu = (float)u[head * 64 + i];
+    const float kk = dt_load(n, dt_index4(n, i, head, t, 0));
+    const float rr = dt_load(r, dt_index(r, i, head, t));
+    const float xx = wave_sum(uu * kk * rr);
+    const float vv = dt_load(n, dt_index4(n, i, head, t, 1));
+    const size_t o = dt_index(x, i, head, t);
+    dt_store(x, o, dt_load(x, o) + xx * vv);
+}
+
+void time_first_v7(hipStream_t s, const void* u, DTensor r, DTensor n, DTensor x) {
+    if (r.shape[2] == 0) return;
+    dim3 grid(r.shape[1], r.shape[2]);
+    time_first_v7_kernel<<<grid, 64, 0, s>>>((const f16*)u, r, n, x);
+}
+
+// ------------------------------------------------------------------ channel_mix (V7) (channel_mix.wgsl:83-107)
+__global__ void __launch_bounds__(256) channel_mix_v7_kernel(const uint32_t* __restrict__ cursors, DTensor st, DTensor v, DTensor x) {
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t stack = blockIdx.y;
+    if (c >= x.shape[0]) return;
+    const Cursor cur = unpack_cursor(cursors[stack]);
+    const size_t o = dt_index(x, c, stack, 0);
+    if (stack - cur.token + 1 == cur.len) dt_store(st, dt_index(st, c, 0, cur.batch), dt_load(x, o));
+    dt_store(x, o, dt_load(v, dt_index(v, c, stack, 0)));
+}
+
+void channel_mix_v7(hipStream_t s, const uint32_t* cursors, DTensor st, DTensor v, DTensor x) {
+    if (x.shape[1] == 0) return;
+    dim3 grid((x.shape[0] + 255) / 256, x.shape[1]);
+    channel_mix_v7_kernel<<<grid, 256, 0, s>>>(cursors, st, v, x);
+}
+
+// ------------------------------------------------------------------ softmax (softmax.wgsl) -- next (f)1
+__global__ void __launch_bounds__(256) softmax_kernel(DTensor x) {
+    __shared__ float red[4];
+    const uint32_t C = x.shape[0];
+    const size_t base = dt_index(x, 0, blockIdx.x, blockIdx.y);
+    float m = -3.0e38f;
+    for (uint32_t i = threadIdx.x; i < C; i += 256) m = fmaxf(m, dt_load(x, base + i));
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float s = 0.0f;
+    for (uint32_t i = threadIdx.x; i < C; i += 256) s += __expf(dt_load(x, base + i) - m);
+    s = block_sum<4>(s, red);
+    for (uint32_t i = threadIdx.x; i < C; i += 256) dt_store(x, base + i, __expf(dt_load(x, base + i) - m) / s);
+}
+
+void softmax(hipStream_t s, DTensor x) {
+    if (x.shape[1] == 0 || x.shape[2] == 0) return;
+    dim3 grid(x.shape[1], x.shape[2]);
+    softmax_kernel<<<grid, 256, 0, s>>>(x);
+}
+
+// ------------------------------------------------------------------ embedding gather / header gather / argmax
+// RnnJob::load gathers embedding rows on the CPU (v7.rs:438-474); with the f16 table resident on the
+// device the same rows are gathered here (values identical, one 2*D-byte row per token).
+__global__ void __launch_bounds__(256) gather_rows_f16_kernel(const f16* __restrict__ table, const uint32_t* __restrict__ ids,
+                                                               f16* __restrict__ out, uint32_t d) {
+    const uint32_t t = blockIdx.y;
+    const size_t row = ids[t];
+    for (uint32_t c = blockIdx.x * 256 + threadIdx.x; c < d; c += gridDim.x * 256) out[(size_t)t * d + c] = table[row * d + c];
+}
+
+void gather_rows_f16(hipStream_t s, const void* table, const uint32_t* ids, void* out, uint32_t d, uint32_t n) {
+    if (n == 0) return;
+    dim3 grid((d + 255) / 256, n);
+    gather_rows_f16_kernel<<<grid, 256, 0, s>>>((const f16*)table, ids, (f16*)out, d);
+}
+
+// RnnRedirect::op (rnn.rs:101-134): copy the header rows of x into head_x
+__global__ void __launch_bounds__(256) gather_rows_any_kernel(DTensor in, const uint32_t* __restrict__ rows, DTensor out) {
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= out.shape[0]) return;
+    dt_store(out, dt_index(out, c, blockIdx.y, 0), dt_load(in, dt_index(in, c, rows[blockIdx.y], 0)));
+}
+
+void gather_rows_any(hipStream_t s, DTensor in, const uint32_t* rows, DTensor out, uint32_t n) {
+    if (n == 0) return;
+    dim3 grid((out.shape[0] + 255) / 256, n);
+    gather_rows_any_kernel<<<grid, 256, 0, s>>>(in, rows, out);
+}
+
+// greedy sampling on device: first index of the maximum (the reference's `sample(&output, 0.0)` after
+// softmax picks the arg-max probability; softmax is monotone so the logits' argmax is the same token)
+__global__ void __launch_bounds__(1024) argmax_rows_kernel(const float* __restrict__ logits, uint32_t v, uint32_t v_stride,
+                                                            uint32_t* __restrict__ out) {
+    __shared__ float smax[16];
+    __shared__ uint32_t sidx[16];
+    const float* row = logits + (size_t)blockIdx.x * v_stride;
+    float best = -3.0e38f;
+    uint32_t bi = 0xffffffffu;
+    for (uint32_t i = threadIdx.x; i < v; i += 1024) {
+        const float x = row[i];
+        if (x > best) { best = x; bi = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, WAVE);
+        const uint32_t oi = __shfl_xor(bi, o, WAVE);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { smax[threadIdx.x >> 6] = best; sidx[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 16; ++k)
+            if (smax[k] > best || (smax[k] == best && sidx[k] < bi)) { best = smax[k]; bi = sidx[k]; }
+        out[blockIdx.x] = bi == 0xffffffffu ? 0u : bi;
+    }
+}
+
+void argmax_rows(hipStream_t s, const float* logits, uint32_t v, uint32_t v_stride, uint32_t n, uint32_t* out) {
+    if (n == 0) return;
+    argmax_rows_kernel<<<n, 1024, 0, s>>>(logits, v, v_stride, out);
+}
+
+}  // namespace wrk

@@ -1,0 +1,59 @@
+// Internal definitions of the RWKV-7 model / state handles.
+#pragma once
+#include <map>
+#include <tuple>
+#include <vector>
+
+#include "wrk_internal.h"
+
+struct wrk_v7_state {
+    wrk_ctx* ctx = nullptr;
+    uint32_t num_layer = 0, num_emb = 0, head_size = 0, num_batch = 0;
+    float* data = nullptr;      // [L][B][S+2][D] f32 == L tensors [D, S+2, B] (v7.rs:514-527)
+    size_t layer_elems() const { return (size_t)num_batch * (head_size + 2) * num_emb; }
+    float* layer_ptr(uint32_t l) const { return data + layer_elems() * l; }
+};
+
+struct V7Scratch {      // Runtime<f16> + Header<f16> (v7.rs:281-383); f16 unless noted
+    void *input, *x, *att_x, *att_v0, *rx, *wx, *kx, *vx, *ax, *gx, *r, *w, *k, *v, *a, *g, *o, *kk, *vv, *n;
+    void *aux_w, *aux_a, *aux_g, *aux_v, *ffn_x, *ffn_kx, *ffn_k, *ffn_v, *ln_tmp, *head_x;
+    float* head_o;      // f32 [V, num_header]
+    uint32_t *cursors, *tokens, *headers, *argmax, *counter;
+};
+
+struct wrk_v7_model {
+    wrk_ctx* ctx = nullptr;
+    wrk_v7_model_desc d{};
+    std::vector<wrk_v7_layer_desc> layers;
+    const wrk_buf *ln0_w = nullptr, *ln0_b = nullptr, *ln_out_w = nullptr, *ln_out_b = nullptr, *emb = nullptr;
+    const wrk_matrix* head = nullptr;
+
+    void* scratch = nullptr;
+    uint32_t scratch_tokens = 0, scratch_headers = 0;
+    V7Scratch s{};
+    uint32_t* history = nullptr;    // generated tokens [steps][B] (device)
+    size_t history_cap = 0;
+
+    struct GraphKey {
+        const void* state; uint32_t b, mode;
+        bool operator<(const GraphKey& o) const { return std::tie(state, b, mode) < std::tie(o.state, o.b, o.mode); }
+    };
+    std::map<GraphKey, wrk_program*> graphs;
+
+    // fused decode path (wrk_v7_fused.hip)
+    void* fused = nullptr;
+
+    int32_t ensure_scratch(uint32_t T, uint32_t NH);
+    int32_t ensure_history(size_t n);
+    void drop_graphs();
+    int32_t enqueue_ops(wrk_v7_state* st, uint32_t T, uint32_t NH, bool identity_headers);
+    int32_t enqueue_fused_decode(wrk_v7_state* st, uint32_t B, uint32_t NH, bool identity_headers);
+    void free_fused();
+};
+
+int32_t wrk_buf_write_raw(wrk_ctx* ctx, void* dst, const void* src, size_t bytes);
+
+namespace wrk {
+// tokens <- argmax; history[counter][b] = argmax[b]; counter += 1   (one tiny kernel)
+void advance_tokens(hipStream_t s, const uint32_t* argmax, uint32_t* tokens, uint32_t* history, uint32_t* counter, uint32_t b);
+}

@@ -1,0 +1,455 @@
+// RWKV-7 model runner behind wrk_v7_* (include/wrk_hip.h).
+//
+// mode 0 ("op-by-op") enqueues exactly the TensorOp list that v7::Bundle::dispatch builds
+// (src/runtime/v7.rs:598-713, dispatch_layer :716-1007, dispatch_header :1009-1036), one kernel per
+// reference op, on scratch buffers laid out like `Runtime<f16>` (v7.rs:281-364).
+// mode 1 ("fused") runs the decode fast path of wrk_v7_fused.hip when every sequence of the chunk
+// contributes exactly one token, and falls back to mode 0 otherwise (prefill chunks).
+#include "wrk_internal.h"
+#include "wrk_v7.h"
+
+#define LOCK(ctx) std::lock_guard<std::recursive_mutex> _lk((ctx)->mu)
+
+static constexpr float LN_EPS = 1.0e-5f;    // v7.rs:47
+static constexpr float GN_EPS = 64.0e-5f;   // v7.rs:48
+static constexpr float L2_EPS = 1.0e-12f;   // v7.rs:46
+
+static inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// ------------------------------------------------------------------ scratch ("Runtime<f16>" + "Header<f16>")
+int32_t wrk_v7_model::ensure_scratch(uint32_t T, uint32_t NH) {
+    if (T <= scratch_tokens && NH <= scratch_headers && scratch) return WRK_OK;
+    if (ctx->capturing) return wrk_fail(ctx, WRK_E_ARG, "scratch must be sized before capture");
+    const uint32_t nt = T > scratch_tokens ? T : scratch_tokens;
+    const uint32_t nh = NH > scratch_headers ? NH : scratch_headers;
+    WRK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    drop_graphs();                                   // captured graphs hold the old pointers
+    if (scratch) hipFree(scratch);
+    scratch = nullptr;
+    const size_t D = d.num_emb, F = d.num_hidden, V = d.num_vocab;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += up256(bytes); return o; };
+    const size_t vecT = D * nt * 2;
+    size_t o_named[32];
+    int ni = 0;
+    for (int i = 0; i < 23; ++i) o_named[ni++] = take(vecT);          // input, x, att_x, att_v0, 6 shifted, r w k v a g o, kk, vv, ffn_x, ffn_kx, ffn_v, spare
+    const size_t o_n = take(vecT * 4);
+    const size_t o_auxw = take((size_t)d.lora_w * nt * 2), o_auxa = take((size_t)d.lora_a * nt * 2);
+    const size_t o_auxg = take((size_t)d.lora_g * nt * 2), o_auxv = take((size_t)d.lora_v * nt * 2);
+    const size_t o_ffnk = take(F * nt * 2);
+    const size_t o_headx = take(D * nh * 2), o_heado = take(V * nh * 4);
+    const size_t o_cur = take((size_t)nt * 4), o_tok = take((size_t)nt * 4), o_hdr = take((size_t)nh * 4), o_arg = take((size_t)nh * 4);
+    const size_t o_cnt = take(256);
+    WRK_HIP(ctx, hipMalloc(&scratch, off));
+    WRK_HIP(ctx, hipMemsetAsync(scratch, 0, off, ctx->stream));
+    char* b = (char*)scratch;
+    ni = 0;
+    s.input = b + o_named[ni++]; s.x = b + o_named[ni++]; s.att_x = b + o_named[ni++]; s.att_v0 = b + o_named[ni++];
+    s.rx = b + o_named[ni++]; s.wx = b + o_named[ni++]; s.kx = b + o_named[ni++]; s.vx = b + o_named[ni++];
+    s.ax = b + o_named[ni++]; s.gx = b + o_named[ni++];
+    s.r = b + o_named[ni++]; s.w = b + o_named[ni++]; s.k = b + o_named[ni++]; s.v = b + o_named[ni++];
+    s.a = b + o_named[ni++]; s.g = b + o_named[ni++]; s.o = b + o_named[ni++];
+    s.kk = b + o_named[ni++]; s.vv = b + o_named[ni++];
+    s.ffn_x = b + o_named[ni++]; s.ffn_kx = b + o_named[ni++]; s.ffn_v = b + o_named[ni++]; s.ln_tmp = b + o_named[ni++];
+    s.n = b + o_n;
+    s.aux_w = b + o_auxw; s.aux_a = b + o_auxa; s.aux_g = b + o_auxg; s.aux_v = b + o_auxv;
+    s.ffn_k = b + o_ffnk;
+    s.head_x = b + o_headx; s.head_o = (float*)(b + o_heado);
+    s.cursors = (uint32_t*)(b + o_cur); s.tokens = (uint32_t*)(b + o_tok); s.headers = (uint32_t*)(b + o_hdr); s.argmax = (uint32_t*)(b + o_arg);
+    s.counter = (uint32_t*)(b + o_cnt);
+    scratch_tokens = nt;
+    scratch_headers = nh;
+    return WRK_OK;
+}
+
+static wrk::MatJob mj(const wrk_matrix* m, DTensor in, DTensor out, uint32_t act) {
+    return wrk::MatJob{m->data, m->aux, m->kind, m->flags, m->k, m->m, (uint32_t)m->row_bytes, in, out, act, 0};
+}
+
+static int32_t mm(wrk_ctx* ctx, const wrk_matrix* m, DTensor in, DTensor out, uint32_t act) {
+    wrk::MatJob j = mj(m, in, out, act);
+    int rc = -2;
+    if (in.shape[1] * in.shape[2] >= 16) rc = wrk::matmul_mfma(ctx->stream, j, ctx->num_cu);
+    if (rc == -2) rc = wrk::matvec(ctx->stream, &j, 1, ctx->num_cu);
+    if (rc != 0) return wrk_fail(ctx, WRK_E_ARG, "matmul launch rejected (K=%u M=%u)", m->k, m->m);
+    return WRK_OK;
+}
+#define MM(...)                                   \
+    do {                                          \
+        int32_t _r = mm(ctx, __VA_ARGS__);        \
+        if (_r != WRK_OK) return _r;              \
+    } while (0)
+
+// ------------------------------------------------------------------ mode 0: the reference op list
+int32_t wrk_v7_model::enqueue_ops(wrk_v7_state* st, uint32_t T, uint32_t NH, bool identity_headers) {
+    hipStream_t q = ctx->stream;
+    const uint32_t D = d.num_emb, F = d.num_hidden, H = d.num_head, S = D / H, V = d.num_vocab;
+    auto vec = [&](void* p, uint32_t c = 0) { return make_dense(p, WRK_F16, c ? c : D, T); };
+    auto heads = [&](void* p) { return make_dense(p, WRK_F16, S, H, T); };
+    DTensor x = vec(s.x), att_x = vec(s.att_x), v0 = vec(s.att_v0);
+    DTensor rx = vec(s.rx), wx = vec(s.wx), kx = vec(s.kx), vx = vec(s.vx), ax = vec(s.ax), gx = vec(s.gx);
+    DTensor r = vec(s.r), w = vec(s.w), k = vec(s.k), v = vec(s.v), a = vec(s.a), g = vec(s.g), o = vec(s.o);
+    DTensor kk = vec(s.kk), vv = vec(s.vv);
+    DTensor ffn_x = vec(s.ffn_x), ffn_kx = vec(s.ffn_kx), ffn_v = vec(s.ffn_v), ffn_k = vec(s.ffn_k, F);
+    DTensor aux_w = vec(s.aux_w, d.lora_w), aux_a = vec(s.aux_a, d.lora_a), aux_g = vec(s.aux_g, d.lora_g), aux_v = vec(s.aux_v, d.lora_v);
+    DTensor n4 = make_dense(s.n, WRK_F16, S, H, T, 4);
+    auto nslice = [&](uint32_t i) { DTensor t = make_dense(s.n, WRK_F16, D, T, 4); t.shape[2] = 1; t.offset[2] = i; return t; };
+    auto bvec = [&](const wrk_buf* b) { return make_dense(b->ptr, WRK_F16, D, 1, 1); };
+
+    // embed: LN(ln0) in place on the gathered rows, blit to x (v7.rs:649-659)
+    DTensor input = vec(s.input);
+    wrk::layer_norm(q, ln0_w->ptr, ln0_b->ptr, input, LN_EPS);
+    wrk::blit(q, input, x);
+
+    for (uint32_t li = 0; li < d.num_layer; ++li) {
+        const wrk_v7_layer_desc& L = layers[li];
+        // state views (v7.rs:198-208): att = rows 0..S, ffn = row S+1 of [D, S+2, B]
+        DTensor st_att = make_dense(st->layer_ptr(li), WRK_F32, D, S + 2, st->num_batch);
+        st_att.shape[1] = S + 1;
+        DTensor st_row0 = st_att; st_row0.shape[1] = 1;
+        DTensor st_ffn = make_dense(st->layer_ptr(li), WRK_F32, D, S + 2, st->num_batch);
+        st_ffn.shape[1] = 1; st_ffn.offset[1] = S + 1;
+
+        wrk::blit(q, x, att_x);                                                          // 1
+        wrk::layer_norm(q, L.ln1_w->ptr, L.ln1_b->ptr, att_x, LN_EPS);                   // 2
+        wrk::token_shift(q, s.cursors, L.x_r->ptr, st_row0, att_x, rx, 1);               // 3
+        wrk::token_shift(q, s.cursors, L.x_w->ptr, st_row0, att_x, wx, 1);
+        wrk::token_shift(q, s.cursors, L.x_k->ptr, st_row0, att_x, kx, 1);
+        wrk::token_shift(q, s.cursors, L.x_v->ptr, st_row0, att_x, vx, 1);
+        wrk::token_shift(q, s.cursors, L.x_a->ptr, st_row0, att_x, ax, 1);
+        wrk::token_shift(q, s.cursors, L.x_g->ptr, st_row0, att_x, gx, 1);
+        MM(L.w_r, rx, r, WRK_ACT_NONE);                                                  // 4
+        MM(L.w_k, kx, k, WRK_ACT_NONE);
+        MM(L.w_v, vx, v, WRK_ACT_NONE);
+        MM(L.w1, wx, aux_w, WRK_ACT_TANH);                                               // 5
+        MM(L.w2, aux_w, w, WRK_ACT_NONE);
+        wrk::binary(q, 0, bvec(L.w0), w, 0, 0, 0);
+        MM(L.a1, ax, aux_a, WRK_ACT_NONE);                                               // 6
+        MM(L.a2, aux_a, a, WRK_ACT_NONE);
+        wrk::binary(q, 0, bvec(L.a0), a, 0, 0, WRK_ACT_SIGMOID);
+        MM(L.g1, gx, aux_g, WRK_ACT_SIGMOID);                                            // 7
+        MM(L.g2, aux_g, g, WRK_ACT_NONE);
+        wrk::blit(q, k, kk);                                                             // 8
+        wrk::binary(q, 1, bvec(L.k_k), kk, 0, 0, 0);
+        wrk::l2_norm(q, heads(s.kk), L2_EPS);
+        wrk::control_k_v7(q, L.k_a->ptr, a, k);                                          // 9
+        if (li == 0) {                                                                   // 10
+            wrk::blit(q, v, v0);
+        } else {
+            MM(L.v1, vx, aux_v, WRK_ACT_NONE);
+            MM(L.v2, aux_v, vv, WRK_ACT_NONE);
+            wrk::binary(q, 0, bvec(L.v0), vv, 0, 0, WRK_ACT_SIGMOID);
+            wrk::lerp(q, v0, v, vv, 1);
+        }
+        wrk::blit(q, k, nslice(0));                                                      // 11
+        wrk::blit(q, v, nslice(1));
+        wrk::blit(q, a, nslice(2));
+        wrk::blit(q, kk, nslice(3));
+        wrk::time_mix_v7(q, s.cursors, st_att, heads(s.r), heads(s.w), n4, heads(s.att_x));   // 12
+        wrk::group_norm(q, L.gn_w->ptr, L.gn_b->ptr, heads(s.att_x), GN_EPS);            // 13
+        wrk::time_first_v7(q, L.r_k->ptr, heads(s.r), n4, heads(s.att_x));               // 14
+        wrk::binary(q, 1, g, att_x, 0, 0, 0);                                            // 15
+        MM(L.w_o, att_x, o, WRK_ACT_NONE);                                               // 16
+        wrk::binary(q, 0, o, x, 0, 0, 0);
+        wrk::blit(q, x, ffn_x);                                                          // 17
+        wrk::layer_norm(q, L.ln2_w->ptr, L.ln2_b->ptr, ffn_x, LN_EPS);
+        wrk::token_shift(q, s.cursors, L.ffn_x_k->ptr, st_ffn, ffn_x, ffn_kx, 1);        // 18
+        MM(L.ffn_w_k, ffn_kx, ffn_k, WRK_ACT_SQUARED_RELU);                              // 19
+        MM(L.ffn_w_v, ffn_k, ffn_v, WRK_ACT_NONE);                                       // 20
+        wrk::channel_mix_v7(q, s.cursors, st_ffn, ffn_v, ffn_x);                         // 21
+        wrk::binary(q, 0, ffn_x, x, 0, 0, 0);                                            // 22
+        if ((li + 1) % d.rescale == 0) wrk::affine(q, x, 0.5f, 0.0f);                    // 23
+    }
+    // header (v7.rs:1009-1036): gather header rows, LN(ln_out), head matmul into f32 logits
+    if (NH > 0) {
+        DTensor head_x = make_dense(s.head_x, WRK_F16, D, NH);
+        if (identity_headers) wrk::blit(q, make_dense(s.x, WRK_F16, D, NH), head_x);
+        else wrk::gather_rows_any(q, x, s.headers, head_x, NH);
+        wrk::layer_norm(q, ln_out_w->ptr, ln_out_b->ptr, head_x, LN_EPS);
+        MM(head, head_x, make_dense(s.head_o, WRK_F32, V, NH), WRK_ACT_NONE);
+    }
+    WRK_LAUNCH_CHECK(ctx);
+    return WRK_OK;
+}
+
+// ------------------------------------------------------------------ C ABI
+extern "C" {
+
+int32_t wrk_v7_model_create(wrk_ctx* ctx, const wrk_v7_model_desc* desc, wrk_v7_model** out) {
+    if (!ctx || !desc || !out) return WRK_E_ARG;
+    LOCK(ctx);
+    *out = nullptr;
+    WRK_ARG(ctx, desc->num_layer >= 1 && desc->num_head >= 1 && desc->num_emb % desc->num_head == 0, "bad model dims");
+    WRK_ARG(ctx, desc->num_emb / desc->num_head == 64, "head size must be 64");
+    WRK_ARG(ctx, desc->layers && desc->head && desc->ln0_w && desc->ln0_b && desc->ln_out_w && desc->ln_out_b, "missing tensors");
+    WRK_ARG(ctx, desc->head->k == desc->num_emb && desc->head->m >= desc->num_vocab, "head matrix shape mismatch");
+    const uint32_t D = desc->num_emb, F = desc->num_hidden;
+    for (uint32_t l = 0; l < desc->num_layer; ++l) {
+        const wrk_v7_layer_desc& L = desc->layers[l];
+        const wrk_buf* vecs[] = {L.ln1_w, L.ln1_b, L.ln2_w, L.ln2_b, L.x_r, L.x_w, L.x_k, L.x_v, L.x_a, L.x_g, L.w0, L.a0,
+                                 L.r_k, L.k_k, L.k_a, L.gn_w, L.gn_b, L.ffn_x_k};
+        for (const wrk_buf* b : vecs) WRK_ARG(ctx, b && b->bytes >= (size_t)D * 2, "layer %u: vector missing or shorter than D f16", l);
+        struct { const wrk_matrix* m; uint32_t k, mm; } mats[] = {
+            {L.w1, D, desc->lora_w}, {L.w2, desc->lora_w, D}, {L.a1, D, desc->lora_a}, {L.a2, desc->lora_a, D},
+            {L.g1, D, desc->lora_g}, {L.g2, desc->lora_g, D}, {L.w_k, D, D}, {L.w_v, D, D}, {L.w_r, D, D}, {L.w_o, D, D},
+            {L.ffn_w_k, D, F}, {L.ffn_w_v, F, D}};
+        for (auto& e : mats) WRK_ARG(ctx, e.m && e.m->k == e.k && e.m->m == e.mm, "layer %u: matrix missing or wrong shape (want K=%u M=%u)", l, e.k, e.mm);
+        if (l > 0) {
+            WRK_ARG(ctx, L.v0 && L.v0->bytes >= (size_t)D * 2, "layer %u: v0 missing", l);
+            WRK_ARG(ctx, L.v1 && L.v1->k == D && L.v1->m == desc->lora_v && L.v2 && L.v2->k == desc->lora_v && L.v2->m == D, "layer %u: v1/v2 wrong shape", l);
+        }
+    }
+    wrk_v7_model* m = new wrk_v7_model();
+    m->ctx = ctx;
+    m->d = *desc;
+    m->d.rescale = desc->rescale ? desc->rescale : 1024;
+    m->layers.assign(desc->layers, desc->layers + desc->num_layer);
+    m->d.layers = m->layers.data();
+    m->ln0_w = desc->ln0_w; m->ln0_b = desc->ln0_b; m->ln_out_w = desc->ln_out_w; m->ln_out_b = desc->ln_out_b;
+    m->emb = desc->emb_f16; m->head = desc->head;
+    // retain every handle (the Rust side keeps Arc clones inside v7::Model)
+    auto rb = [](const wrk_buf* b) { if (b) const_cast<wrk_buf*>(b)->refs.fetch_add(1); };
+    auto rm = [](const wrk_matrix* x) { if (x) const_cast<wrk_matrix*>(x)->refs.fetch_add(1); };
+    rb(m->ln0_w); rb(m->ln0_b); rb(m->ln_out_w); rb(m->ln_out_b); rb(m->emb); rm(m->head);
+    for (auto& L : m->layers) {
+        const wrk_buf* vecs[] = {L.ln1_w, L.ln1_b, L.ln2_w, L.ln2_b, L.x_r, L.x_w, L.x_k, L.x_v, L.x_a, L.x_g, L.w0, L.a0, L.v0,
+                                 L.r_k, L.k_k, L.k_a, L.gn_w, L.gn_b, L.ffn_x_k};
+        for (const wrk_buf* b : vecs) rb(b);
+        const wrk_matrix* mats[] = {L.w1, L.w2, L.a1, L.a2, L.g1, L.g2, L.v1, L.v2, L.w_k, L.w_v, L.w_r, L.w_o, L.ffn_w_k, L.ffn_w_v};
+        for (const wrk_matrix* x : mats) rm(x);
+    }
+    *out = m;
+    return WRK_OK;
+}
+
+int32_t wrk_v7_model_destroy(wrk_v7_model* m) {
+    if (!m) return WRK_E_ARG;
+    wrk_ctx* ctx = m->ctx;
+    {
+        LOCK(ctx);
+        hipSetDevice(ctx->device);
+        hipStreamSynchronize(ctx->stream);
+        for (auto& kv : m->graphs) wrk_program_destroy(kv.second);
+        if (m->scratch) hipFree(m->scratch);
+        m->free_fused();
+    }
+    auto fb = [](const wrk_buf* b) { if (b) wrk_buf_release(const_cast<wrk_buf*>(b)); };
+    auto fm = [](const wrk_matrix* x) { if (x) wrk_matrix_release(const_cast<wrk_matrix*>(x)); };
+    fb(m->ln0_w); fb(m->ln0_b); fb(m->ln_out_w); fb(m->ln_out_b); fb(m->emb); fm(m->head);
+    for (auto& L : m->layers) {
+        const wrk_buf* vecs[] = {L.ln1_w, L.ln1_b, L.ln2_w, L.ln2_b, L.x_r, L.x_w, L.x_k, L.x_v, L.x_a, L.x_g, L.w0, L.a0, L.v0,
+                                 L.r_k, L.k_k, L.k_a, L.gn_w, L.gn_b, L.ffn_x_k};
+        for (const wrk_buf* b : vecs) fb(b);
+        const wrk_matrix* mats[] = {L.w1, L.w2, L.a1, L.a2, L.g1, L.g2, L.v1, L.v2, L.w_k, L.w_v, L.w_r, L.w_o, L.ffn_w_k, L.ffn_w_v};
+        for (const wrk_matrix* x : mats) fm(x);
+    }
+    delete m;
+    return WRK_OK;
+}
+
+// A = sum(weight tensors read per token) + 2*L*D*(S+2)*4*B + B*(D*2 + V*4)
+size_t wrk_v7_model_token_bytes(const wrk_v7_model* m, uint32_t B) {
+    if (!m) return 0;
+    const size_t D = m->d.num_emb, S = D / m->d.num_head, V = m->d.num_vocab;
+    size_t w = wrk_matrix_stream_bytes(m->head) + 4 * D * 2;     // head + ln0/ln_out vectors
+    for (uint32_t l = 0; l < m->d.num_layer; ++l) {
+        const wrk_v7_layer_desc& L = m->layers[l];
+        const wrk_matrix* mats[] = {L.w1, L.w2, L.a1, L.a2, L.g1, L.g2, L.w_k, L.w_v, L.w_r, L.w_o, L.ffn_w_k, L.ffn_w_v};
+        for (const wrk_matrix* x : mats) w += wrk_matrix_stream_bytes(x);
+        if (l > 0) w += wrk_matrix_stream_bytes(L.v1) + wrk_matrix_stream_bytes(L.v2) + D * 2;
+        w += 18 * D * 2;                                         // f16 vectors of the layer
+    }
+    return w + 2 * (size_t)m->d.num_layer * D * (S + 2) * 4 * B + (size_t)B * (D * 2 + V * 4);
+}
+
+int32_t wrk_v7_state_create(wrk_ctx* ctx, const wrk_v7_model* model, uint32_t num_batch, wrk_v7_state** out) {
+    if (!ctx || !model || !out) return WRK_E_ARG;
+    LOCK(ctx);
+    *out = nullptr;
+    WRK_ARG(ctx, num_batch >= 1 && num_batch <= 255, "num_batch must be 1..255 (cursor batch is u8, tensor/mod.rs:53-60)");
+    WRK_HIP(ctx, hipSetDevice(ctx->device));
+    wrk_v7_state* st = new wrk_v7_state();
+    st->ctx = ctx;
+    st->num_layer = model->d.num_layer;
+    st->num_emb = model->d.num_emb;
+    st->head_size = model->d.num_emb / model->d.num_head;
+    st->num_batch = num_batch;
+    const size_t bytes = st->layer_elems() * st->num_layer * 4;
+    hipError_t e = hipMalloc((void**)&st->data, bytes);
+    if (e == hipSuccess) e = hipMemsetAsync(st->data, 0, bytes, ctx->stream);
+    if (e != hipSuccess) { delete st; return wrk_fail(ctx, e == hipErrorOutOfMemory ? WRK_E_OOM : WRK_E_HIP, "state alloc: %s", hipGetErrorString(e)); }
+    *out = st;
+    return WRK_OK;
+}
+
+int32_t wrk_v7_state_destroy(wrk_v7_state* st) {
+    if (!st) return WRK_E_ARG;
+    {
+        LOCK(st->ctx);
+        hipSetDevice(st->ctx->device);
+        hipStreamSynchronize(st->ctx->stream);
+        hipFree(st->data);
+    }
+    delete st;
+    return WRK_OK;
+}
+
+// host layout [L][S+2][D] (reference shape [D, S+2, L, 1], x fastest); device [L][B][S+2][D]
+int32_t wrk_v7_state_load(wrk_ctx* ctx, wrk_v7_state* st, uint32_t batch, const float* src) {
+    if (!ctx || !st || !src) return WRK_E_ARG;
+    LOCK(ctx);
+    WRK_ARG(ctx, batch < st->num_batch, "batch %u out of range", batch);
+    WRK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t per = (size_t)(st->head_size + 2) * st->num_emb;
+    for (uint32_t l = 0; l < st->num_layer; ++l)
+        WRK_HIP(ctx, hipMemcpyAsync(st->layer_ptr(l) + batch * per, src + l * per, per * 4, hipMemcpyHostToDevice, ctx->stream));
+    WRK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return WRK_OK;
+}
+
+int32_t wrk_v7_state_back(wrk_ctx* ctx, const wrk_v7_state* st, uint32_t batch, float* dst) {
+    if (!ctx || !st || !dst) return WRK_E_ARG;
+    LOCK(ctx);
+    WRK_ARG(ctx, batch < st->num_batch, "batch %u out of range", batch);
+    WRK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t per = (size_t)(st->head_size + 2) * st->num_emb;
+    for (uint32_t l = 0; l < st->num_layer; ++l)
+        WRK_HIP(ctx, hipMemcpyAsync(dst + l * per, st->layer_ptr(l) + batch * per, per * 4, hipMemcpyDeviceToHost, ctx->stream));
+    WRK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return WRK_OK;
+}
+
+int32_t wrk_v7_infer(wrk_ctx* ctx, wrk_v7_model* m, wrk_v7_state* st, const uint32_t* tokens, const uint16_t* emb_rows,
+                     const uint32_t* cursors, uint32_t T, const uint32_t* headers, uint32_t NH, float* logits, uint32_t* argmax,
+                     uint32_t mode) {
+    if (!ctx || !m || !st) return WRK_E_ARG;
+    LOCK(ctx);
+    WRK_HIP(ctx, hipSetDevice(ctx->device));
+    if (T == 0) return WRK_OK;                                  // v7.rs:626-635: empty job
+    WRK_ARG(ctx, cursors, "cursors required");
+    WRK_ARG(ctx, tokens || emb_rows, "either token ids or gathered embedding rows are required");
+    WRK_ARG(ctx, !tokens || m->emb, "token ids given but the model has no device embedding table");
+    WRK_ARG(ctx, NH == 0 || headers, "headers required");
+    WRK_ARG(ctx, st->num_emb == m->d.num_emb && st->num_layer == m->d.num_layer, "state does not belong to this model");
+    const uint32_t D = m->d.num_emb, V = m->d.num_vocab;
+    // validate cursors / tokens / headers on the host: a bad index would fault the GPU
+    uint32_t nseq = 0;
+    bool one_token_each = true;
+    for (uint32_t t = 0; t < T; ++t) {
+        const uint32_t c = cursors[t], b = c & 0xff, tok = (c >> 8) & 0xffff, len = c >> 24;
+        WRK_ARG(ctx, b < st->num_batch, "cursor %u: batch %u >= %u", t, b, st->num_batch);
+        WRK_ARG(ctx, len >= 1 && tok <= t && t < tok + len && tok + len <= T, "cursor %u: bad range (token %u len %u)", t, tok, len);
+        if (tok == t) ++nseq;
+        if (len != 1) one_token_each = false;
+        if (tokens) WRK_ARG(ctx, tokens[t] < V, "token %u: id %u >= vocab %u", t, tokens[t], V);
+    }
+    bool identity = (NH == T);
+    for (uint32_t h = 0; h < NH; ++h) {
+        WRK_ARG(ctx, headers[h] < T, "header %u: row %u >= %u tokens", h, headers[h], T);
+        if (headers[h] != h) identity = false;
+    }
+    int32_t rc = m->ensure_scratch(T, NH ? NH : 1);
+    if (rc != WRK_OK) return rc;
+    rc = wrk_buf_write_raw(ctx, m->s.cursors, cursors, (size_t)T * 4);
+    if (rc != WRK_OK) return rc;
+    if (NH) { rc = wrk_buf_write_raw(ctx, m->s.headers, headers, (size_t)NH * 4); if (rc != WRK_OK) return rc; }
+    if (tokens) {
+        rc = wrk_buf_write_raw(ctx, m->s.tokens, tokens, (size_t)T * 4);
+        if (rc != WRK_OK) return rc;
+        wrk::gather_rows_f16(ctx->stream, m->emb->ptr, m->s.tokens, m->s.input, D, T);
+    } else {
+        rc = wrk_buf_write_raw(ctx, m->s.input, emb_rows, (size_t)T * D * 2);
+        if (rc != WRK_OK) return rc;
+    }
+    if (mode == 1 && one_token_each && nseq == T) rc = m->enqueue_fused_decode(st, T, NH, identity);
+    else rc = m->enqueue_ops(st, T, NH, identity);
+    if (rc != WRK_OK) return rc;
+    if (NH && argmax) wrk::argmax_rows(ctx->stream, m->s.head_o, V, V, NH, m->s.argmax);
+    WRK_LAUNCH_CHECK(ctx);
+    if (NH && logits) WRK_HIP(ctx, hipMemcpyAsync(logits, m->s.head_o, (size_t)NH * V * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (NH && argmax) WRK_HIP(ctx, hipMemcpyAsync(argmax, m->s.argmax, (size_t)NH * 4, hipMemcpyDeviceToHost, ctx->stream));
+    WRK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return WRK_OK;
+}
+
+int32_t wrk_v7_generate_greedy(wrk_ctx* ctx, wrk_v7_model* m, wrk_v7_state* st, const uint32_t* first_tokens, uint32_t B,
+                               uint32_t steps, uint32_t* out_tokens, float* last_logits, float* elapsed_ms, uint32_t mode) {
+    if (!ctx || !m || !st || !first_tokens) return WRK_E_ARG;
+    LOCK(ctx);
+    WRK_HIP(ctx, hipSetDevice(ctx->device));
+    WRK_ARG(ctx, m->emb, "generate_greedy needs the device embedding table");
+    WRK_ARG(ctx, B >= 1 && B <= st->num_batch, "num_batch %u exceeds the state's %u", B, st->num_batch);
+    WRK_ARG(ctx, st->num_emb == m->d.num_emb && st->num_layer == m->d.num_layer, "state does not belong to this model");
+    const uint32_t D = m->d.num_emb, V = m->d.num_vocab;
+    for (uint32_t b = 0; b < B; ++b) WRK_ARG(ctx, first_tokens[b] < V, "first token %u out of vocab", first_tokens[b]);
+    if (elapsed_ms) *elapsed_ms = 0.0f;
+    if (steps == 0) return WRK_OK;
+    int32_t rc = m->ensure_scratch(B, B);
+    if (rc != WRK_OK) return rc;
+    rc = m->ensure_history((size_t)steps * B);
+    if (rc != WRK_OK) return rc;
+    std::vector<uint32_t> cur(B), hdr(B);
+    for (uint32_t b = 0; b < B; ++b) { cur[b] = b | (b << 8) | (1u << 24); hdr[b] = b; }
+    rc = wrk_buf_write_raw(ctx, m->s.cursors, cur.data(), (size_t)B * 4);
+    if (rc == WRK_OK) rc = wrk_buf_write_raw(ctx, m->s.headers, hdr.data(), (size_t)B * 4);
+    if (rc == WRK_OK) rc = wrk_buf_write_raw(ctx, m->s.tokens, first_tokens, (size_t)B * 4);
+    if (rc != WRK_OK) return rc;
+    WRK_HIP(ctx, hipMemsetAsync(m->s.counter, 0, 4, ctx->stream));
+    WRK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+
+    // one graph per (state, B, mode): the analogue of the reference's cached RnnJob for a repeated RnnInfo
+    const wrk_v7_model::GraphKey key{st, B, mode};
+    wrk_program* prog = nullptr;
+    auto it = m->graphs.find(key);
+    if (it != m->graphs.end()) prog = it->second;
+    else {
+        rc = wrk_capture_begin(ctx);
+        if (rc != WRK_OK) return rc;
+        wrk::gather_rows_f16(ctx->stream, m->emb->ptr, m->s.tokens, m->s.input, D, B);
+        rc = (mode == 1) ? m->enqueue_fused_decode(st, B, B, true) : m->enqueue_ops(st, B, B, true);
+        if (rc == WRK_OK) {
+            wrk::argmax_rows(ctx->stream, m->s.head_o, V, V, B, m->s.argmax);
+            wrk::advance_tokens(ctx->stream, m->s.argmax, m->s.tokens, m->history, m->s.counter, B);
+        }
+        wrk_program* p = nullptr;
+        int32_t rc2 = wrk_capture_end(ctx, &p);
+        if (rc != WRK_OK) { if (p) wrk_program_destroy(p); return rc; }
+        if (rc2 != WRK_OK) return rc2;
+        prog = p;
+        m->graphs[key] = prog;
+    }
+    hipEvent_t e0, e1;
+    WRK_HIP(ctx, hipEventCreate(&e0));
+    WRK_HIP(ctx, hipEventCreate(&e1));
+    WRK_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    for (uint32_t i = 0; i < steps; ++i) WRK_HIP(ctx, hipGraphLaunch(prog->exec, ctx->stream));
+    WRK_HIP(ctx, hipEventRecord(e1, ctx->stream));
+    WRK_HIP(ctx, hipEventSynchronize(e1));
+    float ms = 0.0f;
+    WRK_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    if (elapsed_ms) *elapsed_ms = ms;
+    if (out_tokens) WRK_HIP(ctx, hipMemcpyAsync(out_tokens, m->history, (size_t)steps * B * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (last_logits) WRK_HIP(ctx, hipMemcpyAsync(last_logits, m->s.head_o, (size_t)B * V * 4, hipMemcpyDeviceToHost, ctx->stream));
+    WRK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return WRK_OK;
+}
+
+}  // extern "C"
+
+int32_t wrk_v7_model::ensure_history(size_t n) {
+    if (n <= history_cap && history) return WRK_OK;
+    WRK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    drop_graphs();
+    if (history) hipFree(history);
+    history = nullptr;
+    WRK_HIP(ctx, hipMalloc((void**)&history, n * 4 + 256));
+    history_cap = n;
+    return WRK_OK;
+}
+
+int32_t wrk_buf_write_raw(wrk_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    wrk_buf tmp{ctx, dst, bytes, {1}};
+    return wrk_buf_write(ctx, &tmp, 0, src, bytes);
+}
