@@ -153,6 +153,8 @@ struct MatJob {
     DTensor out;            // [M, T, B]
     uint32_t act;
     uint32_t sparse;
+    uint32_t has_res = 0;   // fused `add`: out = round_to_out_dtype(act(W.x)) + res
+    DTensor res{};
 };
 int matvec(hipStream_t s, const MatJob* jobs, int njobs, int num_cu);
 int matmul_mfma(hipStream_t s, const MatJob& job, int num_cu);

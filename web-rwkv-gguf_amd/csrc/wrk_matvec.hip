@@ -316,7 +316,8 @@ struct JobDev {
     const uint8_t* w;
     uint32_t kind, flags, k, m, row_bytes, act;
     uint32_t rows_per_wg, wg_begin;    // first workgroup (in x) of this job
-    DTensor in, out;
+    uint32_t has_res;                  // fused residual: out = round_out(act(acc)) + res   (matmul + TensorOp::add)
+    DTensor in, out, res;
 };
 
 struct MatvecParams {
@@ -405,7 +406,9 @@ __global__ void __launch_bounds__(256) matvec_kernel(const MatvecParams P) {
             const uint32_t tk = tok0 + n;
             if (lane == 0 && tk < ntok) {
                 const uint32_t t = tk % J.in.shape[1], b = tk / J.in.shape[1];
-                dt_store(J.out, dt_index(J.out, r, t, b), act_apply(J.act, v));
+                float o = act_apply(J.act, v);
+                if (J.has_res) o = dt_round(J.out, o) + dt_load(J.res, dt_index(J.res, r, t, b));
+                dt_store(J.out, dt_index(J.out, r, t, b), o);
             }
         }
     }
@@ -442,7 +445,7 @@ int matvec(hipStream_t s, const MatJob* jobs, int njobs, int num_cu) {
         JobDev& d = P.jobs[j];
         d.w = jobs[j].w; d.kind = jobs[j].kind; d.flags = jobs[j].flags; d.k = jobs[j].k; d.m = jobs[j].m;
         d.row_bytes = jobs[j].row_bytes; d.act = jobs[j].act; d.rows_per_wg = rpw; d.wg_begin = wg;
-        d.in = jobs[j].in; d.out = jobs[j].out;
+        d.in = jobs[j].in; d.out = jobs[j].out; d.res = jobs[j].res; d.has_res = jobs[j].has_res;
         wg += (jobs[j].m + rpw - 1) / rpw;
     }
     const uint32_t kpad = (kmax + 15u) & ~15u;

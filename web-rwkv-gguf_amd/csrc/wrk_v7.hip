@@ -335,11 +335,16 @@ int32_t wrk_v7_infer(wrk_ctx* ctx, wrk_v7_model* m, wrk_v7_state* st, const uint
     // validate cursors / tokens / headers on the host: a bad index would fault the GPU
     uint32_t nseq = 0;
     bool one_token_each = true;
+    std::vector<uint8_t> seen(256, 0);
     for (uint32_t t = 0; t < T; ++t) {
         const uint32_t c = cursors[t], b = c & 0xff, tok = (c >> 8) & 0xffff, len = c >> 24;
         WRK_ARG(ctx, b < st->num_batch, "cursor %u: batch %u >= %u", t, b, st->num_batch);
         WRK_ARG(ctx, len >= 1 && tok <= t && t < tok + len && tok + len <= T, "cursor %u: bad range (token %u len %u)", t, tok, len);
-        if (tok == t) ++nseq;
+        if (tok == t) {
+            ++nseq;
+            WRK_ARG(ctx, !seen[b], "cursor %u: batch %u appears in two chunks of one dispatch", t, b);   // two writers of one state slice
+            seen[b] = 1;
+        }
         if (len != 1) one_token_each = false;
         if (tokens) WRK_ARG(ctx, tokens[t] < V, "token %u: id %u >= vocab %u", t, tokens[t], V);
     }
@@ -397,32 +402,43 @@ int32_t wrk_v7_generate_greedy(wrk_ctx* ctx, wrk_v7_model* m, wrk_v7_state* st, 
     WRK_HIP(ctx, hipMemsetAsync(m->s.counter, 0, 4, ctx->stream));
     WRK_HIP(ctx, hipStreamSynchronize(ctx->stream));
 
-    // one graph per (state, B, mode): the analogue of the reference's cached RnnJob for a repeated RnnInfo
+    // one graph per (state, B, mode): the analogue of the reference's cached RnnJob for a repeated RnnInfo.
+    // WRK_NO_GRAPH=1 enqueues every step eagerly instead (used under rocprofv3 kernel tracing).
+    const char* ng = getenv("WRK_NO_GRAPH");
+    const bool eager = ng && ng[0] == '1';
+    auto enqueue_step = [&]() -> int32_t {
+        wrk::gather_rows_f16(ctx->stream, m->emb->ptr, m->s.tokens, m->s.input, D, B);
+        int32_t r = (mode == 1) ? m->enqueue_fused_decode(st, B, B, true) : m->enqueue_ops(st, B, B, true);
+        if (r != WRK_OK) return r;
+        wrk::argmax_rows(ctx->stream, m->s.head_o, V, V, B, m->s.argmax);
+        wrk::advance_tokens(ctx->stream, m->s.argmax, m->s.tokens, m->history, m->s.counter, B);
+        return WRK_OK;
+    };
     const wrk_v7_model::GraphKey key{st, B, mode};
     wrk_program* prog = nullptr;
-    auto it = m->graphs.find(key);
-    if (it != m->graphs.end()) prog = it->second;
-    else {
-        rc = wrk_capture_begin(ctx);
-        if (rc != WRK_OK) return rc;
-        wrk::gather_rows_f16(ctx->stream, m->emb->ptr, m->s.tokens, m->s.input, D, B);
-        rc = (mode == 1) ? m->enqueue_fused_decode(st, B, B, true) : m->enqueue_ops(st, B, B, true);
-        if (rc == WRK_OK) {
-            wrk::argmax_rows(ctx->stream, m->s.head_o, V, V, B, m->s.argmax);
-            wrk::advance_tokens(ctx->stream, m->s.argmax, m->s.tokens, m->history, m->s.counter, B);
+    if (!eager) {
+        auto it = m->graphs.find(key);
+        if (it != m->graphs.end()) prog = it->second;
+        else {
+            rc = wrk_capture_begin(ctx);
+            if (rc != WRK_OK) return rc;
+            rc = enqueue_step();
+            wrk_program* p = nullptr;
+            int32_t rc2 = wrk_capture_end(ctx, &p);
+            if (rc != WRK_OK) { if (p) wrk_program_destroy(p); return rc; }
+            if (rc2 != WRK_OK) return rc2;
+            prog = p;
+            m->graphs[key] = prog;
         }
-        wrk_program* p = nullptr;
-        int32_t rc2 = wrk_capture_end(ctx, &p);
-        if (rc != WRK_OK) { if (p) wrk_program_destroy(p); return rc; }
-        if (rc2 != WRK_OK) return rc2;
-        prog = p;
-        m->graphs[key] = prog;
     }
     hipEvent_t e0, e1;
     WRK_HIP(ctx, hipEventCreate(&e0));
     WRK_HIP(ctx, hipEventCreate(&e1));
     WRK_HIP(ctx, hipEventRecord(e0, ctx->stream));
-    for (uint32_t i = 0; i < steps; ++i) WRK_HIP(ctx, hipGraphLaunch(prog->exec, ctx->stream));
+    for (uint32_t i = 0; i < steps; ++i) {
+        if (eager) { rc = enqueue_step(); if (rc != WRK_OK) return rc; }
+        else WRK_HIP(ctx, hipGraphLaunch(prog->exec, ctx->stream));
+    }
     WRK_HIP(ctx, hipEventRecord(e1, ctx->stream));
     WRK_HIP(ctx, hipEventSynchronize(e1));
     float ms = 0.0f;
