@@ -155,7 +155,10 @@ struct MatJob {
     uint32_t sparse;
     uint32_t has_res = 0;   // fused `add`: out = round_to_out_dtype(act(W.x)) + res
     DTensor res{};
+    float* amax_val = nullptr;      // optional fused arg-max partials [num_wg][ntok]
+    uint32_t* amax_idx = nullptr;
 };
+uint32_t matvec_num_wg(const MatJob* jobs, int njobs, int num_cu, uint32_t* rows_per_wg);
 int matvec(hipStream_t s, const MatJob* jobs, int njobs, int num_cu);
 int matmul_mfma(hipStream_t s, const MatJob& job, int num_cu);
 size_t repack_row_bytes(uint32_t kind, uint32_t k);

@@ -171,142 +171,148 @@ __device__ __forceinline__ float group_dot(Group& g, const f16* __restrict__ xs,
     return g.scale * dot16(g.q, xs + g.xoff) - g.minv * xsum[g.xoff >> 4];
 }
 
-// ------------------------------------------------------------------ per-kind chunk decoders
-// Every decoder handles chunk `c` (16 bytes of the quant plane) of one row and returns the
-// contribution for each of the NB staged input vectors.
-
 template <bool R16, int NB>
-__device__ __forceinline__ void chunk_q4k(const uint8_t* __restrict__ row, uint32_t nb, uint32_t c, const f16* xs, const float* xsum,
-                                          uint32_t kpad, float (&acc)[NB]) {
-    const uint32_t b = c >> 3, sub = c & 7u, j = sub >> 1, h = sub & 1u;
-    const u32x4 w = __builtin_nontemporal_load((const u32x4*)(row + (size_t)c * 16));
-    const u32x4 hd = *(const u32x4*)(row + (size_t)nb * 128 + (size_t)b * 16);
-    const float d = f16bits_to_f32(hd.x & 0xffffu), dmin = f16bits_to_f32(hd.x >> 16);
-    float sc0, m0, sc1, m1;
-    scale_min_k4(2 * j, hd.y, hd.z, hd.w, sc0, m0);
-    scale_min_k4(2 * j + 1, hd.y, hd.z, hd.w, sc1, m1);
-    Group lo, hi;
-    const f16x2 bias = h2(1024.0f);
-    bytes_to_h2(w.x & 0x0f0f0f0fu, bias, lo.q[0], lo.q[1]);
-    bytes_to_h2(w.y & 0x0f0f0f0fu, bias, lo.q[2], lo.q[3]);
-    bytes_to_h2(w.z & 0x0f0f0f0fu, bias, lo.q[4], lo.q[5]);
-    bytes_to_h2(w.w & 0x0f0f0f0fu, bias, lo.q[6], lo.q[7]);
-    bytes_to_h2((w.x >> 4) & 0x0f0f0f0fu, bias, hi.q[0], hi.q[1]);
-    bytes_to_h2((w.y >> 4) & 0x0f0f0f0fu, bias, hi.q[2], hi.q[3]);
-    bytes_to_h2((w.z >> 4) & 0x0f0f0f0fu, bias, hi.q[4], hi.q[5]);
-    bytes_to_h2((w.w >> 4) & 0x0f0f0f0fu, bias, hi.q[6], hi.q[7]);
-    lo.scale = d * sc0; lo.minv = dmin * m0; lo.xoff = b * 256 + j * 64 + h * 16;
-    hi.scale = d * sc1; hi.minv = dmin * m1; hi.xoff = lo.xoff + 32;
+__device__ __forceinline__ void groups_accumulate(const Group& lo, const Group& hi, bool two, const f16* xs, const float* xsum,
+                                                  uint32_t kpad, float (&acc)[NB]) {
 #pragma unroll
     for (int n = 0; n < NB; ++n) {
-        Group l2 = lo, h2g = hi;
+        Group l2 = lo;
         acc[n] += group_dot<R16>(l2, xs + (size_t)n * kpad, xsum + (size_t)n * (kpad >> 4));
-        acc[n] += group_dot<R16>(h2g, xs + (size_t)n * kpad, xsum + (size_t)n * (kpad >> 4));
+        if (two) {
+            Group h2g = hi;
+            acc[n] += group_dot<R16>(h2g, xs + (size_t)n * kpad, xsum + (size_t)n * (kpad >> 4));
+        }
     }
 }
 
-template <bool R16, int NB>
-__device__ __forceinline__ void chunk_q5k(const uint8_t* __restrict__ row, uint32_t nb, uint32_t c, const f16* xs, const float* xsum,
-                                          uint32_t kpad, float (&acc)[NB]) {
-    const uint32_t b = c >> 3, sub = c & 7u, j = sub >> 1, h = sub & 1u;
-    const u32x4 w = __builtin_nontemporal_load((const u32x4*)(row + (size_t)c * 16));
-    const u32x4 qh = *(const u32x4*)(row + (size_t)nb * 128 + (size_t)b * 32 + h * 16);
-    const u32x4 hd = *(const u32x4*)(row + (size_t)nb * 160 + (size_t)b * 16);
-    const float d = f16bits_to_f32(hd.x & 0xffffu), dmin = f16bits_to_f32(hd.x >> 16);
-    float sc0, m0, sc1, m1;
-    scale_min_k4(2 * j, hd.y, hd.z, hd.w, sc0, m0);
-    scale_min_k4(2 * j + 1, hd.y, hd.z, hd.w, sc1, m1);
-    const uint32_t s0 = 2 * j, s1 = 2 * j + 1;
-    Group lo, hi;
-    const f16x2 bias = h2(1024.0f);
-#define Q5LO(W, H) (((W) & 0x0f0f0f0fu) | ((((H) >> s0) & 0x01010101u) << 4))
-#define Q5HI(W, H) ((((W) >> 4) & 0x0f0f0f0fu) | ((((H) >> s1) & 0x01010101u) << 4))
-    bytes_to_h2(Q5LO(w.x, qh.x), bias, lo.q[0], lo.q[1]);
-    bytes_to_h2(Q5LO(w.y, qh.y), bias, lo.q[2], lo.q[3]);
-    bytes_to_h2(Q5LO(w.z, qh.z), bias, lo.q[4], lo.q[5]);
-    bytes_to_h2(Q5LO(w.w, qh.w), bias, lo.q[6], lo.q[7]);
-    bytes_to_h2(Q5HI(w.x, qh.x), bias, hi.q[0], hi.q[1]);
-    bytes_to_h2(Q5HI(w.y, qh.y), bias, hi.q[2], hi.q[3]);
-    bytes_to_h2(Q5HI(w.z, qh.z), bias, hi.q[4], hi.q[5]);
-    bytes_to_h2(Q5HI(w.w, qh.w), bias, hi.q[6], hi.q[7]);
-#undef Q5LO
-#undef Q5HI
-    lo.scale = d * sc0; lo.minv = dmin * m0; lo.xoff = b * 256 + j * 64 + h * 16;
-    hi.scale = d * sc1; hi.minv = dmin * m1; hi.xoff = lo.xoff + 32;
-#pragma unroll
-    for (int n = 0; n < NB; ++n) {
-        Group l2 = lo, h2g = hi;
-        acc[n] += group_dot<R16>(l2, xs + (size_t)n * kpad, xsum + (size_t)n * (kpad >> 4));
-        acc[n] += group_dot<R16>(h2g, xs + (size_t)n * kpad, xsum + (size_t)n * (kpad >> 4));
-    }
+// ------------------------------------------------------------------ per-kind chunk load / decode
+// A chunk is 16 bytes of a row's quant plane.  `load_raw` only ISSUES the global loads of chunk c
+// (quants non-temporal: each weight byte is read once per token; side data through the caches),
+// `dot_raw` decodes and accumulates -- split so the next chunk's loads are in flight while the
+// current one is decoded, and so the first chunk is requested before the inputs are staged.
+struct Raw {
+    u32x4 w;    // quant chunk
+    u32x4 a;    // Q4_K: header | Q5_K: high bits | Q6_K: high bits | Q8_0: a.x = d bits
+    u32x4 b;    // Q5_K: header | Q6_K: b.x = sc_lo | sc_hi << 8 | d bits << 16
+};
+
+template <int KIND>
+__device__ __forceinline__ uint32_t num_chunks(uint32_t k, uint32_t kpad) {
+    return KIND == WRK_MAT_F16 ? (kpad >> 3) : (KIND == WRK_MAT_Q8_0 ? (k >> 4) : (k >> 8) * 8);
 }
 
-template <bool R16, int NB>
-__device__ __forceinline__ void chunk_q6k(const uint8_t* __restrict__ row, uint32_t nb, uint32_t c, const f16* xs, const float* xsum,
-                                          uint32_t kpad, float (&acc)[NB]) {
-    const uint32_t b = c >> 3, sub = c & 7u, n128 = sub >> 2, part = (sub >> 1) & 1u, l0 = (sub & 1u) * 16u;
-    const u32x4 w = __builtin_nontemporal_load((const u32x4*)(row + (size_t)c * 16));
-    const u32x4 qh = *(const u32x4*)(row + (size_t)nb * 128 + (size_t)b * 64 + n128 * 32 + l0);
-    const int8_t* scp = (const int8_t*)(row + (size_t)nb * 192 + (size_t)b * 16 + n128 * 8 + (l0 >> 4) + part * 2);
-    const float sc_lo = (float)scp[0], sc_hi = (float)scp[4];
-    const float d = (float)*(const f16*)(row + (size_t)nb * 208 + (size_t)b * 2);
-    const uint32_t s_lo = part * 2, s_hi = s_lo + 4;
+template <int KIND>
+__device__ __forceinline__ Raw load_raw(const uint8_t* __restrict__ row, uint32_t k, uint32_t c) {
+    Raw r;
+    r.w = __builtin_nontemporal_load((const u32x4*)(row + (size_t)c * 16));
+    const uint32_t nb = k >> 8, b = c >> 3;
+    if (KIND == WRK_MAT_Q4_K) {
+        r.a = *(const u32x4*)(row + (size_t)nb * 128 + (size_t)b * 16);
+    } else if (KIND == WRK_MAT_Q5_K) {
+        r.a = *(const u32x4*)(row + (size_t)nb * 128 + (size_t)b * 32 + (c & 1u) * 16);
+        r.b = *(const u32x4*)(row + (size_t)nb * 160 + (size_t)b * 16);
+    } else if (KIND == WRK_MAT_Q6_K) {
+        const uint32_t sub = c & 7u, n128 = sub >> 2, part = (sub >> 1) & 1u, l0 = (sub & 1u) * 16u;
+        r.a = *(const u32x4*)(row + (size_t)nb * 128 + (size_t)b * 64 + n128 * 32 + l0);
+        const uint8_t* scp = row + (size_t)nb * 192 + (size_t)b * 16 + n128 * 8 + (l0 >> 4) + part * 2;
+        const uint32_t dbits = *(const uint16_t*)(row + (size_t)nb * 208 + (size_t)b * 2);
+        r.b.x = (uint32_t)scp[0] | ((uint32_t)scp[4] << 8) | (dbits << 16);
+    } else if (KIND == WRK_MAT_Q8_0) {
+        r.a.x = *(const uint16_t*)(row + (size_t)k + (size_t)(c >> 1) * 2);
+    }
+    return r;
+}
+
+template <int KIND, bool R16, int NB>
+__device__ __forceinline__ void dot_raw(const Raw& r, uint32_t c, const f16* xs, const float* xsum, uint32_t kpad, float (&acc)[NB]) {
+    const u32x4 w = r.w;
+    if (KIND == WRK_MAT_F16) {
+        const f16x8 wv = __builtin_bit_cast(f16x8, w);
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            const f16x8 x = *(const f16x8*)(xs + (size_t)n * kpad + c * 8);
+            float a = acc[n];
+            a = __builtin_amdgcn_fdot2(__builtin_shufflevector(wv, wv, 0, 1), __builtin_shufflevector(x, x, 0, 1), a, false);
+            a = __builtin_amdgcn_fdot2(__builtin_shufflevector(wv, wv, 2, 3), __builtin_shufflevector(x, x, 2, 3), a, false);
+            a = __builtin_amdgcn_fdot2(__builtin_shufflevector(wv, wv, 4, 5), __builtin_shufflevector(x, x, 4, 5), a, false);
+            a = __builtin_amdgcn_fdot2(__builtin_shufflevector(wv, wv, 6, 7), __builtin_shufflevector(x, x, 6, 7), a, false);
+            acc[n] = a;
+        }
+        return;
+    }
     Group lo, hi;
-    const f16x2 bias = h2(1056.0f);    // 1024 + 32: q6 = code - 32, exact in f16
+    if (KIND == WRK_MAT_Q8_0) {
+        const f16x2 bias = h2(1152.0f);    // 1024 + 128: int8 = (byte ^ 0x80) - 128
+        bytes_to_h2(w.x ^ 0x80808080u, bias, lo.q[0], lo.q[1]);
+        bytes_to_h2(w.y ^ 0x80808080u, bias, lo.q[2], lo.q[3]);
+        bytes_to_h2(w.z ^ 0x80808080u, bias, lo.q[4], lo.q[5]);
+        bytes_to_h2(w.w ^ 0x80808080u, bias, lo.q[6], lo.q[7]);
+        lo.scale = f16bits_to_f32(r.a.x); lo.minv = 0.0f; lo.xoff = c * 16;
+        hi = lo;
+        groups_accumulate<R16, NB>(lo, hi, false, xs, xsum, kpad, acc);
+        return;
+    }
+    const uint32_t b = c >> 3, sub = c & 7u;
+    if (KIND == WRK_MAT_Q6_K) {
+        const uint32_t n128 = sub >> 2, part = (sub >> 1) & 1u, l0 = (sub & 1u) * 16u;
+        const u32x4 qh = r.a;
+        const float sc_lo = (float)(int8_t)(r.b.x & 0xffu), sc_hi = (float)(int8_t)((r.b.x >> 8) & 0xffu);
+        const float d = f16bits_to_f32(r.b.x >> 16);
+        const uint32_t s_lo = part * 2, s_hi = s_lo + 4;
+        const f16x2 bias = h2(1056.0f);    // 1024 + 32: q6 = code - 32, exact in f16
 #define Q6LO(W, H) (((W) & 0x0f0f0f0fu) | ((((H) >> s_lo) & 0x03030303u) << 4))
 #define Q6HI(W, H) ((((W) >> 4) & 0x0f0f0f0fu) | ((((H) >> s_hi) & 0x03030303u) << 4))
-    bytes_to_h2(Q6LO(w.x, qh.x), bias, lo.q[0], lo.q[1]);
-    bytes_to_h2(Q6LO(w.y, qh.y), bias, lo.q[2], lo.q[3]);
-    bytes_to_h2(Q6LO(w.z, qh.z), bias, lo.q[4], lo.q[5]);
-    bytes_to_h2(Q6LO(w.w, qh.w), bias, lo.q[6], lo.q[7]);
-    bytes_to_h2(Q6HI(w.x, qh.x), bias, hi.q[0], hi.q[1]);
-    bytes_to_h2(Q6HI(w.y, qh.y), bias, hi.q[2], hi.q[3]);
-    bytes_to_h2(Q6HI(w.z, qh.z), bias, hi.q[4], hi.q[5]);
-    bytes_to_h2(Q6HI(w.w, qh.w), bias, hi.q[6], hi.q[7]);
+        bytes_to_h2(Q6LO(w.x, qh.x), bias, lo.q[0], lo.q[1]);
+        bytes_to_h2(Q6LO(w.y, qh.y), bias, lo.q[2], lo.q[3]);
+        bytes_to_h2(Q6LO(w.z, qh.z), bias, lo.q[4], lo.q[5]);
+        bytes_to_h2(Q6LO(w.w, qh.w), bias, lo.q[6], lo.q[7]);
+        bytes_to_h2(Q6HI(w.x, qh.x), bias, hi.q[0], hi.q[1]);
+        bytes_to_h2(Q6HI(w.y, qh.y), bias, hi.q[2], hi.q[3]);
+        bytes_to_h2(Q6HI(w.z, qh.z), bias, hi.q[4], hi.q[5]);
+        bytes_to_h2(Q6HI(w.w, qh.w), bias, hi.q[6], hi.q[7]);
 #undef Q6LO
 #undef Q6HI
-    lo.scale = d * sc_lo; lo.minv = 0.0f; lo.xoff = b * 256 + n128 * 128 + part * 32 + l0;
-    hi.scale = d * sc_hi; hi.minv = 0.0f; hi.xoff = lo.xoff + 64;
-#pragma unroll
-    for (int n = 0; n < NB; ++n) {
-        Group l2 = lo, h2g = hi;
-        acc[n] += group_dot<R16>(l2, xs + (size_t)n * kpad, xsum + (size_t)n * (kpad >> 4));
-        acc[n] += group_dot<R16>(h2g, xs + (size_t)n * kpad, xsum + (size_t)n * (kpad >> 4));
+        lo.scale = d * sc_lo; lo.minv = 0.0f; lo.xoff = b * 256 + n128 * 128 + part * 32 + l0;
+        hi.scale = d * sc_hi; hi.minv = 0.0f; hi.xoff = lo.xoff + 64;
+        groups_accumulate<R16, NB>(lo, hi, true, xs, xsum, kpad, acc);
+        return;
     }
-}
-
-template <bool R16, int NB>
-__device__ __forceinline__ void chunk_q80(const uint8_t* __restrict__ row, uint32_t k, uint32_t c, const f16* xs, const float* xsum,
-                                          uint32_t kpad, float (&acc)[NB]) {
-    u32x4 w = __builtin_nontemporal_load((const u32x4*)(row + (size_t)c * 16));
-    const float d = (float)*(const f16*)(row + (size_t)k + (size_t)(c >> 1) * 2);
-    Group g;
-    const f16x2 bias = h2(1152.0f);    // 1024 + 128: int8 = (byte ^ 0x80) - 128
-    bytes_to_h2(w.x ^ 0x80808080u, bias, g.q[0], g.q[1]);
-    bytes_to_h2(w.y ^ 0x80808080u, bias, g.q[2], g.q[3]);
-    bytes_to_h2(w.z ^ 0x80808080u, bias, g.q[4], g.q[5]);
-    bytes_to_h2(w.w ^ 0x80808080u, bias, g.q[6], g.q[7]);
-    g.scale = d; g.minv = 0.0f; g.xoff = c * 16;
-#pragma unroll
-    for (int n = 0; n < NB; ++n) {
-        Group g2 = g;
-        acc[n] += group_dot<R16>(g2, xs + (size_t)n * kpad, xsum + (size_t)n * (kpad >> 4));
+    // Q4_K / Q5_K share the d/dmin/6-bit scale header
+    const uint32_t j = sub >> 1, h = sub & 1u;
+    const u32x4 hd = KIND == WRK_MAT_Q4_K ? r.a : r.b;
+    const float d = f16bits_to_f32(hd.x & 0xffffu), dmin = f16bits_to_f32(hd.x >> 16);
+    float sc0, m0, sc1, m1;
+    scale_min_k4(2 * j, hd.y, hd.z, hd.w, sc0, m0);
+    scale_min_k4(2 * j + 1, hd.y, hd.z, hd.w, sc1, m1);
+    const f16x2 bias = h2(1024.0f);
+    if (KIND == WRK_MAT_Q4_K) {
+        bytes_to_h2(w.x & 0x0f0f0f0fu, bias, lo.q[0], lo.q[1]);
+        bytes_to_h2(w.y & 0x0f0f0f0fu, bias, lo.q[2], lo.q[3]);
+        bytes_to_h2(w.z & 0x0f0f0f0fu, bias, lo.q[4], lo.q[5]);
+        bytes_to_h2(w.w & 0x0f0f0f0fu, bias, lo.q[6], lo.q[7]);
+        bytes_to_h2((w.x >> 4) & 0x0f0f0f0fu, bias, hi.q[0], hi.q[1]);
+        bytes_to_h2((w.y >> 4) & 0x0f0f0f0fu, bias, hi.q[2], hi.q[3]);
+        bytes_to_h2((w.z >> 4) & 0x0f0f0f0fu, bias, hi.q[4], hi.q[5]);
+        bytes_to_h2((w.w >> 4) & 0x0f0f0f0fu, bias, hi.q[6], hi.q[7]);
+    } else {
+        const u32x4 qh = r.a;
+        const uint32_t s0 = 2 * j, s1 = 2 * j + 1;
+#define Q5LO(W, H) (((W) & 0x0f0f0f0fu) | ((((H) >> s0) & 0x01010101u) << 4))
+#define Q5HI(W, H) ((((W) >> 4) & 0x0f0f0f0fu) | ((((H) >> s1) & 0x01010101u) << 4))
+        bytes_to_h2(Q5LO(w.x, qh.x), bias, lo.q[0], lo.q[1]);
+        bytes_to_h2(Q5LO(w.y, qh.y), bias, lo.q[2], lo.q[3]);
+        bytes_to_h2(Q5LO(w.z, qh.z), bias, lo.q[4], lo.q[5]);
+        bytes_to_h2(Q5LO(w.w, qh.w), bias, lo.q[6], lo.q[7]);
+        bytes_to_h2(Q5HI(w.x, qh.x), bias, hi.q[0], hi.q[1]);
+        bytes_to_h2(Q5HI(w.y, qh.y), bias, hi.q[2], hi.q[3]);
+        bytes_to_h2(Q5HI(w.z, qh.z), bias, hi.q[4], hi.q[5]);
+        bytes_to_h2(Q5HI(w.w, qh.w), bias, hi.q[6], hi.q[7]);
+#undef Q5LO
+#undef Q5HI
     }
-}
-
-template <int NB>
-__device__ __forceinline__ void chunk_f16(const uint8_t* __restrict__ row, uint32_t c, const f16* xs, uint32_t kpad, float (&acc)[NB]) {
-    const f16x8 w = __builtin_nontemporal_load((const f16x8*)(row + (size_t)c * 16));
-#pragma unroll
-    for (int n = 0; n < NB; ++n) {
-        const f16x8 x = *(const f16x8*)(xs + (size_t)n * kpad + c * 8);
-        float a = acc[n];
-        a = __builtin_amdgcn_fdot2(__builtin_shufflevector(w, w, 0, 1), __builtin_shufflevector(x, x, 0, 1), a, false);
-        a = __builtin_amdgcn_fdot2(__builtin_shufflevector(w, w, 2, 3), __builtin_shufflevector(x, x, 2, 3), a, false);
-        a = __builtin_amdgcn_fdot2(__builtin_shufflevector(w, w, 4, 5), __builtin_shufflevector(x, x, 4, 5), a, false);
-        a = __builtin_amdgcn_fdot2(__builtin_shufflevector(w, w, 6, 7), __builtin_shufflevector(x, x, 6, 7), a, false);
-        acc[n] = a;
-    }
+    lo.scale = d * sc0; lo.minv = dmin * m0; lo.xoff = b * 256 + j * 64 + h * 16;
+    hi.scale = d * sc1; hi.minv = dmin * m1; hi.xoff = lo.xoff + 32;
+    groups_accumulate<R16, NB>(lo, hi, true, xs, xsum, kpad, acc);
 }
 
 // ------------------------------------------------------------------ the kernel
@@ -318,6 +324,8 @@ struct JobDev {
     uint32_t rows_per_wg, wg_begin;    // first workgroup (in x) of this job
     uint32_t has_res;                  // fused residual: out = round_out(act(acc)) + res   (matmul + TensorOp::add)
     DTensor in, out, res;
+    float* amax_val;                   // optional fused arg-max partials: [num_wg][ntok] (value, row)
+    uint32_t* amax_idx;
 };
 
 struct MatvecParams {
@@ -325,92 +333,133 @@ struct MatvecParams {
     int njobs;
 };
 
-template <int NB>
-__global__ void __launch_bounds__(256) matvec_kernel(const MatvecParams P) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // locate the job of this workgroup
-    int ji = 0;
-#pragma unroll
-    for (int q = 1; q < MAX_JOBS; ++q)
-        if (q < P.njobs && blockIdx.x >= P.jobs[q].wg_begin) ji = q;
-    const JobDev& J = P.jobs[ji];
+template <int KIND, bool R16, int NB>
+__device__ __forceinline__ void matvec_body(const JobDev& J, unsigned char* smem) {
     const uint32_t K = J.k;
     const uint32_t kpad = (K + 15u) & ~15u;
     f16* xs = (f16*)smem;                                   // [NB][kpad]
     float* xsum = (float*)(smem + (size_t)NB * kpad * 2);   // [NB][kpad/16]
-
     const uint32_t ntok = J.in.shape[1] * J.in.shape[2];
     const uint32_t tok0 = blockIdx.y * NB;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t r0 = (blockIdx.x - J.wg_begin) * J.rows_per_wg;
+    const uint32_t r1 = min(r0 + J.rows_per_wg, J.m);
+
+    // work items of this wave: (row, chunk iteration); item it -> row r0 + wave + 4 * (it / iters)
+    const uint32_t nch = num_chunks<KIND>(K, kpad);
+    const uint32_t iters = (nch + 63) >> 6;
+    const uint32_t nrows = r0 + wave < r1 ? (r1 - r0 - wave + 3) >> 2 : 0;
+    const uint32_t nitems = nrows * iters;
+
+    // request the first chunk before touching the inputs: weights do not depend on activations
+    Raw cur{};
+    if (nitems > 0 && lane < nch) cur = load_raw<KIND>(J.w + (size_t)(r0 + wave) * J.row_bytes, K, lane);
 
     // stage inputs (f16) and their per-16 sums
+#pragma unroll
     for (int n = 0; n < NB; ++n) {
         const uint32_t tk = tok0 + n;
         const bool live = tk < ntok;
         const uint32_t t = live ? tk % J.in.shape[1] : 0, b = live ? tk / J.in.shape[1] : 0;
         const size_t base = dt_index(J.in, 0, t, b);
-        for (uint32_t i = tid; i < kpad; i += 256) xs[(size_t)n * kpad + i] = (live && i < K) ? (f16)dt_load(J.in, base + i) : (f16)0.0f;
-    }
-    __syncthreads();
-    for (uint32_t i = tid; i < NB * (kpad >> 4); i += 256) {
-        const f16* p = xs + (size_t)i * 16;
-        float s = 0.0f;
+        f16* xd = xs + (size_t)n * kpad;
+        float* sd = xsum + (size_t)n * (kpad >> 4);
+        if (J.in.dtype == WRK_F16 && ((base | K) & 7u) == 0) {
+            const f16* src = (const f16*)J.in.p + base;
+            for (uint32_t v = tid; v < (kpad >> 3); v += 256) {
+                f16x8 x = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (live && v * 8 < K) x = *(const f16x8*)(src + v * 8);
+                *(f16x8*)(xd + v * 8) = x;
+                float s8 = 0.0f;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) s += (float)p[e];
-        xsum[i] = s;
+                for (int e = 0; e < 8; ++e) s8 += (float)x[e];
+                s8 += __shfl_xor(s8, 1, WAVE);
+                if ((v & 1u) == 0) sd[v >> 1] = s8;
+            }
+        } else {
+            for (uint32_t i = tid; i < kpad; i += 256) xd[i] = (live && i < K) ? (f16)dt_load(J.in, base + i) : (f16)0.0f;
+            __syncthreads();
+            for (uint32_t i = tid; i < (kpad >> 4); i += 256) {
+                float s = 0.0f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) s += (float)xd[i * 16 + e];
+                sd[i] = s;
+            }
+        }
     }
     __syncthreads();
 
-    const uint32_t r0 = (blockIdx.x - J.wg_begin) * J.rows_per_wg;
-    const uint32_t r1 = min(r0 + J.rows_per_wg, J.m);
+    float acc[NB];
+    float best_v[NB];
+    uint32_t best_i[NB];
+#pragma unroll
+    for (int n = 0; n < NB; ++n) { acc[n] = 0.0f; best_v[n] = -3.0e38f; best_i[n] = 0xffffffffu; }
+    for (uint32_t it = 0; it < nitems; ++it) {
+        const uint32_t ri = it / iters, ci = it - ri * iters;
+        const uint32_t r = r0 + wave + 4 * ri, c = lane + 64 * ci;
+        // prefetch the next item
+        Raw nxt{};
+        if (it + 1 < nitems) {
+            const uint32_t it2 = it + 1, ri2 = it2 / iters, ci2 = it2 - ri2 * iters, c2 = lane + 64 * ci2;
+            if (c2 < nch) nxt = load_raw<KIND>(J.w + (size_t)(r0 + wave + 4 * ri2) * J.row_bytes, K, c2);
+        }
+        if (c < nch) dot_raw<KIND, R16, NB>(cur, c, xs, xsum, kpad, acc);
+        if (ci + 1 == iters) {
+#pragma unroll
+            for (int n = 0; n < NB; ++n) {
+                const float v = wave_sum(acc[n]);
+                acc[n] = 0.0f;
+                const uint32_t tk = tok0 + n;
+                if (lane == 0 && tk < ntok) {
+                    const uint32_t t = tk % J.in.shape[1], b = tk / J.in.shape[1];
+                    float o = act_apply(J.act, v);
+                    if (J.has_res) o = dt_round(J.out, o) + dt_load(J.res, dt_index(J.res, r, t, b));
+                    dt_store(J.out, dt_index(J.out, r, t, b), o);
+                    if (o > best_v[n]) { best_v[n] = o; best_i[n] = r; }
+                }
+            }
+        }
+        cur = nxt;
+    }
+    if (J.amax_val) {       // fused greedy sampling, stage 1: per-workgroup (max, first index) of the rows it produced
+        __syncthreads();
+        float* sv = (float*)smem;
+        uint32_t* si = (uint32_t*)(smem + 4 * NB * 4);
+        if (lane == 0) {
+#pragma unroll
+            for (int n = 0; n < NB; ++n) { sv[wave * NB + n] = best_v[n]; si[wave * NB + n] = best_i[n]; }
+        }
+        __syncthreads();
+        if (tid < NB && tok0 + tid < ntok) {
+            float bv = sv[tid];
+            uint32_t bi = si[tid];
+            for (int w = 1; w < 4; ++w) {
+                const float v = sv[w * NB + tid];
+                const uint32_t i2 = si[w * NB + tid];
+                if (v > bv || (v == bv && i2 < bi)) { bv = v; bi = i2; }
+            }
+            const size_t o = (size_t)(blockIdx.x - J.wg_begin) * ntok + tok0 + tid;
+            J.amax_val[o] = bv;
+            J.amax_idx[o] = bi;
+        }
+    }
+}
+
+template <int NB>
+__global__ void __launch_bounds__(256) matvec_kernel(const MatvecParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int ji = 0;
+#pragma unroll
+    for (int q = 1; q < MAX_JOBS; ++q)
+        if (q < P.njobs && blockIdx.x >= P.jobs[q].wg_begin) ji = q;
+    const JobDev& J = P.jobs[ji];
     const bool r16w = (J.flags & WRK_MATRIX_ROUND_F16) != 0;
-    for (uint32_t r = r0 + wave; r < r1; r += 4) {
-        const uint8_t* row = J.w + (size_t)r * J.row_bytes;
-        float acc[NB];
-#pragma unroll
-        for (int n = 0; n < NB; ++n) acc[n] = 0.0f;
-        switch (J.kind) {
-            case WRK_MAT_Q4_K: {
-                const uint32_t nb = K >> 8, nch = nb * 8;
-                if (r16w) for (uint32_t c = lane; c < nch; c += 64) chunk_q4k<true, NB>(row, nb, c, xs, xsum, kpad, acc);
-                else for (uint32_t c = lane; c < nch; c += 64) chunk_q4k<false, NB>(row, nb, c, xs, xsum, kpad, acc);
-                break;
-            }
-            case WRK_MAT_Q5_K: {
-                const uint32_t nb = K >> 8, nch = nb * 8;
-                if (r16w) for (uint32_t c = lane; c < nch; c += 64) chunk_q5k<true, NB>(row, nb, c, xs, xsum, kpad, acc);
-                else for (uint32_t c = lane; c < nch; c += 64) chunk_q5k<false, NB>(row, nb, c, xs, xsum, kpad, acc);
-                break;
-            }
-            case WRK_MAT_Q6_K: {
-                const uint32_t nb = K >> 8, nch = nb * 8;
-                if (r16w) for (uint32_t c = lane; c < nch; c += 64) chunk_q6k<true, NB>(row, nb, c, xs, xsum, kpad, acc);
-                else for (uint32_t c = lane; c < nch; c += 64) chunk_q6k<false, NB>(row, nb, c, xs, xsum, kpad, acc);
-                break;
-            }
-            case WRK_MAT_Q8_0: {
-                const uint32_t nch = K >> 4;
-                if (r16w) for (uint32_t c = lane; c < nch; c += 64) chunk_q80<true, NB>(row, K, c, xs, xsum, kpad, acc);
-                else for (uint32_t c = lane; c < nch; c += 64) chunk_q80<false, NB>(row, K, c, xs, xsum, kpad, acc);
-                break;
-            }
-            default: {   // F16
-                const uint32_t nch = kpad >> 3;
-                for (uint32_t c = lane; c < nch; c += 64) chunk_f16<NB>(row, c, xs, kpad, acc);
-                break;
-            }
-        }
-#pragma unroll
-        for (int n = 0; n < NB; ++n) {
-            const float v = wave_sum(acc[n]);
-            const uint32_t tk = tok0 + n;
-            if (lane == 0 && tk < ntok) {
-                const uint32_t t = tk % J.in.shape[1], b = tk / J.in.shape[1];
-                float o = act_apply(J.act, v);
-                if (J.has_res) o = dt_round(J.out, o) + dt_load(J.res, dt_index(J.res, r, t, b));
-                dt_store(J.out, dt_index(J.out, r, t, b), o);
-            }
-        }
+    switch (J.kind) {
+        case WRK_MAT_Q4_K: if (r16w) matvec_body<WRK_MAT_Q4_K, true, NB>(J, smem); else matvec_body<WRK_MAT_Q4_K, false, NB>(J, smem); break;
+        case WRK_MAT_Q5_K: if (r16w) matvec_body<WRK_MAT_Q5_K, true, NB>(J, smem); else matvec_body<WRK_MAT_Q5_K, false, NB>(J, smem); break;
+        case WRK_MAT_Q6_K: if (r16w) matvec_body<WRK_MAT_Q6_K, true, NB>(J, smem); else matvec_body<WRK_MAT_Q6_K, false, NB>(J, smem); break;
+        case WRK_MAT_Q8_0: if (r16w) matvec_body<WRK_MAT_Q8_0, true, NB>(J, smem); else matvec_body<WRK_MAT_Q8_0, false, NB>(J, smem); break;
+        default: matvec_body<WRK_MAT_F16, false, NB>(J, smem); break;
     }
 }
 
@@ -423,6 +472,19 @@ static int launch_matvec(hipStream_t s, const MatvecParams& P, uint32_t total_wg
     return 0;
 }
 
+uint32_t matvec_num_wg(const MatJob* jobs, int njobs, int num_cu, uint32_t* rows_per_wg) {
+    uint32_t total_rows = 0;
+    for (int j = 0; j < njobs; ++j) total_rows += jobs[j].m;
+    // rows per workgroup: aim at >= 4 workgroups per CU, 4..32 rows (1..8 per wave)
+    uint32_t rpw = (total_rows + (uint32_t)num_cu * 4 - 1) / ((uint32_t)num_cu * 4);
+    rpw = (rpw + 3) & ~3u;
+    rpw = rpw < 4 ? 4 : (rpw > 32 ? 32 : rpw);
+    uint32_t wg = 0;
+    for (int j = 0; j < njobs; ++j) wg += (jobs[j].m + rpw - 1) / rpw;
+    if (rows_per_wg) *rows_per_wg = rpw;
+    return wg;
+}
+
 // All jobs of one call must have the same number of input vectors (T*B); they run in ONE launch.
 int matvec(hipStream_t s, const MatJob* jobs, int njobs, int num_cu) {
     if (njobs <= 0 || njobs > MAX_JOBS) return -1;
@@ -430,29 +492,28 @@ int matvec(hipStream_t s, const MatJob* jobs, int njobs, int num_cu) {
     P.njobs = njobs;
     const uint32_t ntok = jobs[0].in.shape[1] * jobs[0].in.shape[2];
     if (ntok == 0) return 0;
-    uint32_t total_rows = 0, kmax = 0;
+    uint32_t kmax = 0;
     for (int j = 0; j < njobs; ++j) {
         if (jobs[j].in.shape[1] * jobs[j].in.shape[2] != ntok) return -1;
-        total_rows += jobs[j].m;
         kmax = jobs[j].k > kmax ? jobs[j].k : kmax;
     }
-    // rows per workgroup: aim at >= 4 workgroups per CU, 4..32 rows (1..8 per wave)
-    uint32_t rpw = (total_rows + (uint32_t)num_cu * 4 - 1) / ((uint32_t)num_cu * 4);
-    rpw = (rpw + 3) & ~3u;
-    rpw = rpw < 4 ? 4 : (rpw > 32 ? 32 : rpw);
+    uint32_t rpw = 4;
+    matvec_num_wg(jobs, njobs, num_cu, &rpw);
     uint32_t wg = 0;
     for (int j = 0; j < njobs; ++j) {
         JobDev& d = P.jobs[j];
         d.w = jobs[j].w; d.kind = jobs[j].kind; d.flags = jobs[j].flags; d.k = jobs[j].k; d.m = jobs[j].m;
         d.row_bytes = jobs[j].row_bytes; d.act = jobs[j].act; d.rows_per_wg = rpw; d.wg_begin = wg;
         d.in = jobs[j].in; d.out = jobs[j].out; d.res = jobs[j].res; d.has_res = jobs[j].has_res;
+        d.amax_val = jobs[j].amax_val; d.amax_idx = jobs[j].amax_idx;
         wg += (jobs[j].m + rpw - 1) / rpw;
     }
     const uint32_t kpad = (kmax + 15u) & ~15u;
     // pick inputs-per-pass: LDS budget 144 KiB
     int nb = ntok >= 8 ? 8 : (ntok >= 4 ? 4 : (ntok >= 2 ? 2 : 1));
     while (nb > 1 && (size_t)nb * kpad * 2 + (size_t)nb * (kpad >> 4) * 4 > 144 * 1024) nb >>= 1;
-    const size_t smem = (size_t)nb * kpad * 2 + (size_t)nb * (kpad >> 4) * 4;
+    size_t smem = (size_t)nb * kpad * 2 + (size_t)nb * (kpad >> 4) * 4;
+    if (smem < 256) smem = 256;
     const uint32_t groups = (ntok + nb - 1) / nb;
     switch (nb) {
         case 8: return launch_matvec<8>(s, P, wg, groups, smem);

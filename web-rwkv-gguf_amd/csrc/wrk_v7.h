@@ -40,14 +40,19 @@ struct wrk_v7_model {
     };
     std::map<GraphKey, wrk_program*> graphs;
 
-    // fused decode path (wrk_v7_fused.hip)
-    void* fused = nullptr;
+    // fused decode path (wrk_v7_fused.hip): arg-max partials of the head matvec [num_wg][num_header]
+    float* amax_val = nullptr;
+    uint32_t* amax_idx = nullptr;
+    size_t amax_cap = 0;
 
     int32_t ensure_scratch(uint32_t T, uint32_t NH);
     int32_t ensure_history(size_t n);
     void drop_graphs();
     int32_t enqueue_ops(wrk_v7_state* st, uint32_t T, uint32_t NH, bool identity_headers);
-    int32_t enqueue_fused_decode(wrk_v7_state* st, uint32_t B, uint32_t NH, bool identity_headers);
+    // from_tokens: gather embedding rows of s.tokens on the device; want_argmax: greedy token per header row into
+    // s.argmax; advance: also feed it back as the next token (device-resident generation loop)
+    int32_t enqueue_fused_decode(wrk_v7_state* st, uint32_t B, uint32_t NH, bool identity_headers, bool from_tokens,
+                                 bool want_argmax, bool advance);
     void free_fused();
 };
 
@@ -56,4 +61,6 @@ int32_t wrk_buf_write_raw(wrk_ctx* ctx, void* dst, const void* src, size_t bytes
 namespace wrk {
 // tokens <- argmax; history[counter][b] = argmax[b]; counter += 1   (one tiny kernel)
 void advance_tokens(hipStream_t s, const uint32_t* argmax, uint32_t* tokens, uint32_t* history, uint32_t* counter, uint32_t b);
+void argmax_finish(hipStream_t s, const float* pv, const uint32_t* pi, uint32_t nwg, uint32_t ntok, uint32_t* argmax, uint32_t* tokens,
+                   uint32_t* history, uint32_t* counter);
 }

@@ -15,6 +15,7 @@ static constexpr float GN_EPS = 64.0e-5f;   // v7.rs:48
 static constexpr float L2_EPS = 1.0e-12f;   // v7.rs:46
 
 static inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+static wrk::MatJob mj(const wrk_matrix* m, DTensor in, DTensor out, uint32_t act);
 
 // ------------------------------------------------------------------ scratch ("Runtime<f16>" + "Header<f16>")
 int32_t wrk_v7_model::ensure_scratch(uint32_t T, uint32_t NH) {
@@ -59,6 +60,17 @@ int32_t wrk_v7_model::ensure_scratch(uint32_t T, uint32_t NH) {
     s.counter = (uint32_t*)(b + o_cnt);
     scratch_tokens = nt;
     scratch_headers = nh;
+    // arg-max partials of the head matvec: one (value, index) per workgroup and header row
+    {
+        wrk::MatJob hj = mj(head, make_dense(s.head_x, WRK_F16, d.num_emb, nh), make_dense(s.head_o, WRK_F32, d.num_vocab, nh), 0);
+        const size_t need = (size_t)wrk::matvec_num_wg(&hj, 1, ctx->num_cu, nullptr) * nh;
+        if (need > amax_cap) {
+            free_fused();
+            WRK_HIP(ctx, hipMalloc((void**)&amax_val, need * 4));
+            WRK_HIP(ctx, hipMalloc((void**)&amax_idx, need * 4));
+            amax_cap = need;
+        }
+    }
     return WRK_OK;
 }
 
@@ -358,18 +370,21 @@ int32_t wrk_v7_infer(wrk_ctx* ctx, wrk_v7_model* m, wrk_v7_state* st, const uint
     rc = wrk_buf_write_raw(ctx, m->s.cursors, cursors, (size_t)T * 4);
     if (rc != WRK_OK) return rc;
     if (NH) { rc = wrk_buf_write_raw(ctx, m->s.headers, headers, (size_t)NH * 4); if (rc != WRK_OK) return rc; }
+    const bool fused = (mode == 1 && one_token_each && nseq == T);
     if (tokens) {
         rc = wrk_buf_write_raw(ctx, m->s.tokens, tokens, (size_t)T * 4);
         if (rc != WRK_OK) return rc;
-        wrk::gather_rows_f16(ctx->stream, m->emb->ptr, m->s.tokens, m->s.input, D, T);
+        if (!fused) wrk::gather_rows_f16(ctx->stream, m->emb->ptr, m->s.tokens, m->s.input, D, T);
     } else {
         rc = wrk_buf_write_raw(ctx, m->s.input, emb_rows, (size_t)T * D * 2);
         if (rc != WRK_OK) return rc;
     }
-    if (mode == 1 && one_token_each && nseq == T) rc = m->enqueue_fused_decode(st, T, NH, identity);
-    else rc = m->enqueue_ops(st, T, NH, identity);
+    if (fused) rc = m->enqueue_fused_decode(st, T, NH, identity, tokens != nullptr, NH && argmax, false);
+    else {
+        rc = m->enqueue_ops(st, T, NH, identity);
+        if (rc == WRK_OK && NH && argmax) wrk::argmax_rows(ctx->stream, m->s.head_o, V, V, NH, m->s.argmax);
+    }
     if (rc != WRK_OK) return rc;
-    if (NH && argmax) wrk::argmax_rows(ctx->stream, m->s.head_o, V, V, NH, m->s.argmax);
     WRK_LAUNCH_CHECK(ctx);
     if (NH && logits) WRK_HIP(ctx, hipMemcpyAsync(logits, m->s.head_o, (size_t)NH * V * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (NH && argmax) WRK_HIP(ctx, hipMemcpyAsync(argmax, m->s.argmax, (size_t)NH * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -407,8 +422,9 @@ int32_t wrk_v7_generate_greedy(wrk_ctx* ctx, wrk_v7_model* m, wrk_v7_state* st, 
     const char* ng = getenv("WRK_NO_GRAPH");
     const bool eager = ng && ng[0] == '1';
     auto enqueue_step = [&]() -> int32_t {
+        if (mode == 1) return m->enqueue_fused_decode(st, B, B, true, true, true, true);
         wrk::gather_rows_f16(ctx->stream, m->emb->ptr, m->s.tokens, m->s.input, D, B);
-        int32_t r = (mode == 1) ? m->enqueue_fused_decode(st, B, B, true) : m->enqueue_ops(st, B, B, true);
+        int32_t r = m->enqueue_ops(st, B, B, true);
         if (r != WRK_OK) return r;
         wrk::argmax_rows(ctx->stream, m->s.head_o, V, V, B, m->s.argmax);
         wrk::advance_tokens(ctx->stream, m->s.argmax, m->s.tokens, m->history, m->s.counter, B);

@@ -40,9 +40,11 @@ void advance_tokens(hipStream_t s, const uint32_t* argmax, uint32_t* tokens, uin
 }
 
 // ------------------------------------------------------------------ K0 / K4: layer norm + token shifts
+// One workgroup per token.  Every global load (row, LN weights, previous shift state, mix factors)
+// is issued up front as 16-byte vectors: the kernel is one memory round trip + two block reductions.
 struct LnMixParams {
     const f16* src;             // [T][D] rows, or the embedding table when `ids` is set
-    const uint32_t* ids;        // optional row index per token (embedding gather)
+    const uint32_t* ids;        // optional row index per token (embedding gather / header rows)
     const f16 *ln_w, *ln_b;
     float eps;
     uint32_t d, nmix;
@@ -54,37 +56,88 @@ struct LnMixParams {
     const uint32_t* cursors;    // batch id per token
 };
 
+template <int VPT, int NMIX>
 __global__ void __launch_bounds__(256) ln_mix_kernel(const LnMixParams P) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* xs = (float*)smem;           // [D]
     __shared__ float red[4];
-    const uint32_t t = blockIdx.x, D = P.d;
-    const f16* row = P.src + (size_t)(P.ids ? P.ids[t] : t) * D;
+    const uint32_t t = blockIdx.x, D = P.d, nvec = D >> 3, tid = threadIdx.x;
+    const size_t rowi = P.ids ? P.ids[t] : t;
+    const uint32_t batch = P.cursors ? (P.cursors[t] & 0xffu) : t;
+    const f16* row = P.src + rowi * D;
+    float* st = P.state_row ? P.state_row + (size_t)batch * P.state_stride : nullptr;
+    f16x8 xv[VPT], wv[VPT], bv[VPT], mv[NMIX > 0 ? NMIX : 1][VPT];
+    f32x4 pv[VPT][2];
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) {
+        const uint32_t i = tid + 256 * v;
+        if (i < nvec) {
+            xv[v] = *(const f16x8*)(row + i * 8);
+            wv[v] = *(const f16x8*)(P.ln_w + i * 8);
+            bv[v] = *(const f16x8*)(P.ln_b + i * 8);
+            if (NMIX > 0) {
+                pv[v][0] = *(const f32x4*)(st + i * 8);
+                pv[v][1] = *(const f32x4*)(st + i * 8 + 4);
+#pragma unroll
+                for (int m = 0; m < NMIX; ++m) mv[m][v] = *(const f16x8*)(P.mix[m] + i * 8);
+            }
+        }
+    }
     float s = 0.0f;
-    for (uint32_t i = threadIdx.x; i < D; i += 256) { const float v = (float)row[i]; xs[i] = v; s += v; }
+#pragma unroll
+    for (int v = 0; v < VPT; ++v)
+        if (tid + 256 * v < nvec)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += (float)xv[v][e];
     const float mean = block_sum<4>(s, red) / (float)D;
     float q = 0.0f;
-    for (uint32_t i = threadIdx.x; i < D; i += 256) { const float dlt = xs[i] - mean; q += dlt * dlt; }
+#pragma unroll
+    for (int v = 0; v < VPT; ++v)
+        if (tid + 256 * v < nvec)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float dl = (float)xv[v][e] - mean; q += dl * dl; }
     const float var = block_sum<4>(q, red) / (float)D + P.eps;
     const float dev = 1.0f / sqrtf(var);
-    const uint32_t batch = P.cursors ? (P.cursors[t] & 0xffu) : t;
-    float* st = P.state_row ? P.state_row + (size_t)batch * P.state_stride : nullptr;
-    for (uint32_t i = threadIdx.x; i < D; i += 256) {
-        const float value = (xs[i] - mean) * dev;
-        const float y = r16(__builtin_fmaf(value, (float)P.ln_w[i], (float)P.ln_b[i]));   // stored f16 (att_x / ffn_x)
-        if (P.ln_out) P.ln_out[(size_t)t * D + i] = (f16)y;
-        if (st) {
-            const float prev = st[i];
 #pragma unroll
-            for (uint32_t m = 0; m < 6; ++m)
-                if (m < P.nmix) P.out[m][(size_t)t * D + i] = (f16)wgsl_mix(y, prev, (float)P.mix[m][i]);
-            st[i] = y;              // shift-state carry (time_mix_v7.wgsl:156-158 / channel_mix.wgsl:99-101)
+    for (int v = 0; v < VPT; ++v) {
+        const uint32_t i = tid + 256 * v;
+        if (i >= nvec) continue;
+        float y[8];
+        f16x8 yv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float value = ((float)xv[v][e] - mean) * dev;
+            yv[e] = (f16)__builtin_fmaf(value, (float)wv[v][e], (float)bv[v][e]);      // stored f16 (att_x / ffn_x)
+            y[e] = (float)yv[e];
+        }
+        if (P.ln_out) *(f16x8*)(P.ln_out + (size_t)t * D + i * 8) = yv;
+        if (NMIX > 0) {
+#pragma unroll
+            for (int m = 0; m < NMIX; ++m) {
+                f16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (f16)wgsl_mix(y[e], pv[v][e >> 2][e & 3], (float)mv[m][v][e]);
+                *(f16x8*)(P.out[m] + (size_t)t * D + i * 8) = o;
+            }
+            // shift-state carry (time_mix_v7.wgsl:156-158 / channel_mix.wgsl:99-101)
+            f32x4 n0 = {y[0], y[1], y[2], y[3]}, n1 = {y[4], y[5], y[6], y[7]};
+            *(f32x4*)(st + i * 8) = n0;
+            *(f32x4*)(st + i * 8 + 4) = n1;
         }
     }
 }
 
-static void ln_mix(hipStream_t s, const LnMixParams& P, uint32_t T) {
-    ln_mix_kernel<<<T, 256, (size_t)P.d * 4, s>>>(P);
+static int ln_mix(hipStream_t s, const LnMixParams& P, uint32_t T) {
+    const uint32_t nvec = P.d >> 3;
+    const int vpt = nvec <= 256 ? 1 : (nvec <= 512 ? 2 : (nvec <= 1024 ? 4 : 0));
+    if (vpt == 0 || (P.d & 7u)) return -1;
+#define LN_LAUNCH(V, M) ln_mix_kernel<V, M><<<T, 256, 0, s>>>(P)
+#define LN_SWITCH(M) do { if (vpt == 1) LN_LAUNCH(1, M); else if (vpt == 2) LN_LAUNCH(2, M); else LN_LAUNCH(4, M); } while (0)
+    if (P.nmix == 0) LN_SWITCH(0);
+    else if (P.nmix == 1) LN_SWITCH(1);
+    else if (P.nmix == 6) LN_SWITCH(6);
+    else return -1;
+#undef LN_SWITCH
+#undef LN_LAUNCH
+    return 0;
 }
 
 // ------------------------------------------------------------------ K2: the per-head time-mix kernel
@@ -104,13 +157,26 @@ struct HeadParams {
     float gn_eps, l2_eps;
 };
 
-// dot of one f16 weight row slice with an f32 vector in LDS; 4 lanes cooperate on a row
-__device__ __forceinline__ float lora_row_dot(const f16* __restrict__ wrow, const float* __restrict__ aux, uint32_t rank, uint32_t part) {
-    float acc = 0.0f;
-    for (uint32_t c = part * 8; c < rank; c += 32) {
-        const f16x8 w = *(const f16x8*)(wrow + c);
+// dot of a row slice of an f16 [D][rank] matrix with the token's f16 LoRA intermediate; 4 lanes share a
+// row (lane `part` takes columns part*8 + 32*n ..+8).  Weights and inputs are loaded together (no LDS).
+template <int MAXCH>
+__device__ __forceinline__ float lora_row_dot(const f16* __restrict__ wrow, const f16* __restrict__ aux, uint32_t rank, uint32_t part) {
+    f16x8 w[MAXCH], x[MAXCH];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc = __builtin_fmaf((float)w[e], aux[c + e], acc);
+    for (int n = 0; n < MAXCH; ++n) {
+        const uint32_t c = part * 8 + 32 * n;
+        if (c < rank) { w[n] = *(const f16x8*)(wrow + c); x[n] = *(const f16x8*)(aux + c); }
+    }
+    float acc = 0.0f;
+#pragma unroll
+    for (int n = 0; n < MAXCH; ++n) {
+        const uint32_t c = part * 8 + 32 * n;
+        if (c < rank) {
+            acc = __builtin_amdgcn_fdot2(__builtin_shufflevector(w[n], w[n], 0, 1), __builtin_shufflevector(x[n], x[n], 0, 1), acc, false);
+            acc = __builtin_amdgcn_fdot2(__builtin_shufflevector(w[n], w[n], 2, 3), __builtin_shufflevector(x[n], x[n], 2, 3), acc, false);
+            acc = __builtin_amdgcn_fdot2(__builtin_shufflevector(w[n], w[n], 4, 5), __builtin_shufflevector(x[n], x[n], 4, 5), acc, false);
+            acc = __builtin_amdgcn_fdot2(__builtin_shufflevector(w[n], w[n], 6, 7), __builtin_shufflevector(x[n], x[n], 6, 7), acc, false);
+        }
     }
     acc += __shfl_xor(acc, 1, WAVE);
     acc += __shfl_xor(acc, 2, WAVE);
@@ -119,58 +185,55 @@ __device__ __forceinline__ float lora_row_dot(const f16* __restrict__ wrow, cons
 
 __global__ void __launch_bounds__(256) head_kernel(const HeadParams P) {
     constexpr int S = 64;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* aux = (float*)smem;                      // [rw + ra + rg + rv]
     __shared__ float sh_r[S], sh_w[S], sh_k[S], sh_v[S], sh_a[S], sh_b[S], sh_g[S], sh_kk[S];
     __shared__ float sh_red[4][S];
     const uint32_t head = blockIdx.x, t = blockIdx.y, tid = threadIdx.x;
     const uint32_t D = P.d;
     const uint32_t batch = P.cursors[t] & 0xffu;
     const uint32_t c0 = head * S;
+    const uint32_t i = tid & 63, g4 = tid >> 6;
 
-    // 1. LoRA intermediates of this token into LDS
-    const uint32_t o_a = P.rw, o_g = o_a + P.ra, o_v = o_g + P.rg, ntot = o_v + (P.layer0 ? 0 : P.rv);
-    for (uint32_t i = tid; i < ntot; i += 256) {
-        float v;
-        if (i < o_a) v = (float)P.aux_w[(size_t)t * P.rw + i];
-        else if (i < o_g) v = (float)P.aux_a[(size_t)t * P.ra + (i - o_a)];
-        else if (i < o_v) v = (float)P.aux_g[(size_t)t * P.rg + (i - o_g)];
-        else v = (float)P.aux_v[(size_t)t * P.rv + (i - o_v)];
-        aux[i] = v;
-    }
-    __syncthreads();
+    // state of this thread's column slice: S[16*g4 .. +15][i] -- requested first, consumed last
+    float* st = P.state + ((size_t)batch * (S + 2) + 1) * D + c0 + i;
+    float Sreg[16];
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) Sreg[jj] = st[(size_t)(g4 * 16 + jj) * D];
 
-    // 2. up-projections for the 64 channels of this head: thread = (row = tid/4, part = tid%4)
+    // LoRA up-projections for the 64 channels of this head: thread = (row = tid/4, part = tid%4)
     {
         const uint32_t row = tid >> 2, part = tid & 3u, ch = c0 + row;
-        const float dw = lora_row_dot((const f16*)((const uint8_t*)P.w2 + (size_t)ch * P.w2_rb), aux, P.rw, part);
-        const float da = lora_row_dot((const f16*)((const uint8_t*)P.a2 + (size_t)ch * P.a2_rb), aux + o_a, P.ra, part);
-        const float dg = lora_row_dot((const f16*)((const uint8_t*)P.g2 + (size_t)ch * P.g2_rb), aux + o_g, P.rg, part);
+        // per-row scalars (only lane part == 0 uses them; loading in all lanes keeps the loads uniform)
+        const float w0 = (float)P.w0[ch], a0 = (float)P.a0[ch], kkw = (float)P.k_k[ch], kaw = (float)P.k_a[ch];
+        const float kraw = (float)P.k[(size_t)t * D + ch], rraw = (float)P.r[(size_t)t * D + ch];
+        float v = (float)P.v[(size_t)t * D + ch];
+        float v0w = 0.0f, vfirst = 0.0f;
+        if (!P.layer0) { v0w = (float)P.v0[ch]; vfirst = (float)P.v_first[(size_t)t * D + ch]; }
+        const float dw = lora_row_dot<4>((const f16*)((const uint8_t*)P.w2 + (size_t)ch * P.w2_rb), P.aux_w + (size_t)t * P.rw, P.rw, part);
+        const float da = lora_row_dot<4>((const f16*)((const uint8_t*)P.a2 + (size_t)ch * P.a2_rb), P.aux_a + (size_t)t * P.ra, P.ra, part);
+        const float dg = lora_row_dot<16>((const f16*)((const uint8_t*)P.g2 + (size_t)ch * P.g2_rb), P.aux_g + (size_t)t * P.rg, P.rg, part);
         float dv = 0.0f;
-        if (!P.layer0) dv = lora_row_dot((const f16*)((const uint8_t*)P.v2 + (size_t)ch * P.v2_rb), aux + o_v, P.rv, part);
+        if (!P.layer0) dv = lora_row_dot<4>((const f16*)((const uint8_t*)P.v2 + (size_t)ch * P.v2_rb), P.aux_v + (size_t)t * P.rv, P.rv, part);
         if (part == 0) {
-            const float w = r16((float)P.w0[ch] + r16(dw));                              // add(w0, w)
-            const float a = r16(act_sigmoid((float)P.a0[ch] + r16(da)));                 // add_activate(.., Sigmoid)
+            const float w = r16(w0 + r16(dw));                                           // add(w0, w)
+            const float a = r16(act_sigmoid(a0 + r16(da)));                              // add_activate(.., Sigmoid)
             const float g = r16(dg);
-            const float kraw = (float)P.k[(size_t)t * D + ch];
-            float v = (float)P.v[(size_t)t * D + ch];
             if (P.layer0) P.v_first[(size_t)t * D + ch] = (f16)v;                        // blit(att_v, att_v0)
             else {
-                const float vv = r16(act_sigmoid((float)P.v0[ch] + r16(dv)));
-                v = r16(wgsl_mix(v, (float)P.v_first[(size_t)t * D + ch], vv));          // lerp(att_v0, att_v, att_vv, reversed)
+                const float vv = r16(act_sigmoid(v0w + r16(dv)));
+                v = r16(wgsl_mix(v, vfirst, vv));                                        // lerp(att_v0, att_v, att_vv, reversed)
             }
             sh_w[row] = __expf(-0.606531f * act_sigmoid(w));                             // act_w (time_mix_v7.wgsl:68-70)
             sh_a[row] = a;
             sh_g[row] = g;
             sh_v[row] = v;
-            sh_r[row] = (float)P.r[(size_t)t * D + ch];
-            sh_kk[row] = r16((float)P.k_k[ch] * kraw);                                   // mul(k_k, kk)
-            sh_k[row] = r16(kraw * (1.0f + (a - 1.0f) * (float)P.k_a[ch]));             // control_k_v7
+            sh_r[row] = rraw;
+            sh_kk[row] = r16(kkw * kraw);                                                // mul(k_k, kk)
+            sh_k[row] = r16(kraw * (1.0f + (a - 1.0f) * kaw));                           // control_k_v7
         }
     }
+    const float gnw = (float)P.gn_w[c0 + i], gnb = (float)P.gn_b[c0 + i], rkw = (float)P.r_k[c0 + i];
     __syncthreads();
-    // 3. kk <- l2_norm(kk) over the head; a~ = -kk, b~ = kk * a
-    const uint32_t i = tid & 63, g4 = tid >> 6;
+    // kk <- l2_norm(kk) over the head; a~ = -kk, b~ = kk * a
     if (g4 == 0) {
         const float kkv = sh_kk[i];
         const float nrm = 1.0f / sqrtf(wave_sum(kkv * kkv) + P.l2_eps);
@@ -181,11 +244,7 @@ __global__ void __launch_bounds__(256) head_kernel(const HeadParams P) {
     }
     __syncthreads();
 
-    // 4. WKV7: thread (i, g4) owns S[16*g4 .. +15][i] in registers
-    float* st = P.state + ((size_t)batch * (S + 2) + 1) * D + c0 + i;
-    float Sreg[16];
-#pragma unroll
-    for (int jj = 0; jj < 16; ++jj) Sreg[jj] = st[(size_t)(g4 * 16 + jj) * D];
+    // WKV7: thread (i, g4) owns S[16*g4 .. +15][i] in registers
     float sa = 0.0f;
 #pragma unroll
     for (int jj = 0; jj < 16; ++jj) sa = __builtin_fmaf(Sreg[jj], sh_a[g4 * 16 + jj], sa);
@@ -206,18 +265,60 @@ __global__ void __launch_bounds__(256) head_kernel(const HeadParams P) {
     __syncthreads();
     if (g4 == 0) {
         y = r16((sh_red[0][i] + sh_red[1][i]) + (sh_red[2][i] + sh_red[3][i]));          // att_x <- y (f16 store)
-        // 5. group norm over the head (layer_norm.wgsl GROUP_NORM)
+        // group norm over the head (layer_norm.wgsl GROUP_NORM)
         const float mean = wave_sum(y) * (1.0f / S);
         const float dl = y - mean;
         const float var = wave_sum(dl * dl) * (1.0f / S) + P.gn_eps;
-        float o = r16(__builtin_fmaf(dl * (1.0f / sqrtf(var)), (float)P.gn_w[c0 + i], (float)P.gn_b[c0 + i]));
-        // 6. time_first: x += (sum_j r_k * k * r) * v
-        const float xx = wave_sum((float)P.r_k[c0 + i] * sh_k[i] * sh_r[i]);
+        float o = r16(__builtin_fmaf(dl * (1.0f / sqrtf(var)), gnw, gnb));
+        // time_first: x += (sum_j r_k * k * r) * v
+        const float xx = wave_sum(rkw * sh_k[i] * sh_r[i]);
         o = r16(o + xx * vv);
-        // 7. gate
+        // gate
         o = sh_g[i] * o;
         P.out[(size_t)t * D + c0 + i] = (f16)o;
     }
+}
+
+// ------------------------------------------------------------------ greedy sampling, stage 2
+// Reduces the per-workgroup (max, first index) partials written by the head matvec, stores the token,
+// and (optionally) advances the device-resident generation loop: tokens <- argmax, history, counter.
+__global__ void __launch_bounds__(256) argmax_finish_kernel(const float* __restrict__ pv, const uint32_t* __restrict__ pi, uint32_t nwg,
+                                                             uint32_t ntok, uint32_t* __restrict__ argmax, uint32_t* __restrict__ tokens,
+                                                             uint32_t* __restrict__ history, uint32_t* __restrict__ counter) {
+    __shared__ float sv[4];
+    __shared__ uint32_t si[4];
+    const uint32_t step = counter ? *counter : 0;
+    for (uint32_t n = 0; n < ntok; ++n) {
+        float bv = -3.0e38f;
+        uint32_t bi = 0xffffffffu;
+        for (uint32_t w = threadIdx.x; w < nwg; w += 256) {
+            const float v = pv[(size_t)w * ntok + n];
+            const uint32_t i2 = pi[(size_t)w * ntok + n];
+            if (v > bv || (v == bv && i2 < bi)) { bv = v; bi = i2; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, WAVE);
+            const uint32_t oi = __shfl_xor(bi, o, WAVE);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = bv; si[threadIdx.x >> 6] = bi; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int k = 1; k < 4; ++k)
+                if (sv[k] > bv || (sv[k] == bv && si[k] < bi)) { bv = sv[k]; bi = si[k]; }
+            if (bi == 0xffffffffu) bi = 0;
+            argmax[n] = bi;
+            if (tokens) { tokens[n] = bi; history[(size_t)step * ntok + n] = bi; }
+        }
+    }
+    if (counter && threadIdx.x == 0) *counter = step + 1;
+}
+
+void argmax_finish(hipStream_t s, const float* pv, const uint32_t* pi, uint32_t nwg, uint32_t ntok, uint32_t* argmax, uint32_t* tokens,
+                   uint32_t* history, uint32_t* counter) {
+    argmax_finish_kernel<<<1, 256, 0, s>>>(pv, pi, nwg, ntok, argmax, tokens, history, counter);
 }
 
 }  // namespace wrk
@@ -228,31 +329,53 @@ void wrk_v7_model::drop_graphs() {
     graphs.clear();
 }
 
-void wrk_v7_model::free_fused() {}
+void wrk_v7_model::free_fused() {
+    if (amax_val) hipFree(amax_val);
+    if (amax_idx) hipFree(amax_idx);
+    amax_val = nullptr; amax_idx = nullptr; amax_cap = 0;
+}
 
 static wrk::MatJob job(const wrk_matrix* m, DTensor in, DTensor out, uint32_t act) {
     return wrk::MatJob{m->data, m->aux, m->kind, m->flags, m->k, m->m, (uint32_t)m->row_bytes, in, out, act, 0};
 }
 
-int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_t NH, bool identity_headers) {
+int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_t NH, bool identity_headers, bool from_tokens,
+                                            bool want_argmax, bool advance) {
     using namespace wrk;
     hipStream_t q = ctx->stream;
     const uint32_t D = d.num_emb, F = d.num_hidden, H = d.num_head, S = D / H, V = d.num_vocab;
-    // LoRA matrices must be F16 for the head kernel (the reference keeps them Matrix::Fp16, v7.rs:1108-1113)
+    // what the fused kernels assume; anything else takes the op-by-op path
+    bool ok = (D % 8 == 0) && D <= 8192 && d.lora_w % 8 == 0 && d.lora_a % 8 == 0 && d.lora_g % 8 == 0 && d.lora_v % 8 == 0 &&
+              d.lora_w <= 128 && d.lora_a <= 128 && d.lora_v <= 128 && d.lora_g <= 512;
     for (auto& L : layers) {
-        const wrk_matrix* ms[] = {L.w2, L.a2, L.g2, L.v2};
+        const wrk_matrix* ms[] = {L.w2, L.a2, L.g2, L.v2};     // Matrix::Fp16 in the reference (v7.rs:1108-1113)
         for (const wrk_matrix* m : ms)
-            if (m && m->kind != WRK_MAT_F16) return enqueue_ops(st, T, NH, identity_headers);
+            if (m && m->kind != WRK_MAT_F16) ok = false;
     }
-    if (d.lora_w % 8 || d.lora_a % 8 || d.lora_g % 8 || d.lora_v % 8) return enqueue_ops(st, T, NH, identity_headers);
+    if (!ok) {
+        if (from_tokens) gather_rows_f16(q, emb->ptr, s.tokens, s.input, D, T);
+        int32_t rc = enqueue_ops(st, T, NH, identity_headers);
+        if (rc != WRK_OK) return rc;
+        if (want_argmax && NH) {
+            argmax_rows(q, s.head_o, V, V, NH, s.argmax);
+            if (advance) advance_tokens(q, s.argmax, s.tokens, history, s.counter, NH);
+        }
+        return WRK_OK;
+    }
     auto vec = [&](void* p, uint32_t c = 0) { return make_dense(p, WRK_F16, c ? c : D, T); };
+#define LN(P, n)                                                                             \
+    do {                                                                                     \
+        if (ln_mix(q, P, n) != 0) return wrk_fail(ctx, WRK_E_UNSUPPORTED, "ln_mix shape");   \
+    } while (0)
 
-    // embed: LN(ln0) on the gathered rows -> x   (v7.rs:649-659)
+    // embed: gather (device table) + LN(ln0) -> x   (v7.rs:438-474, 649-659)
     {
         LnMixParams P{};
-        P.src = (const f16*)s.input; P.ln_w = (const f16*)ln0_w->ptr; P.ln_b = (const f16*)ln0_b->ptr; P.eps = 1.0e-5f;
+        if (from_tokens) { P.src = (const f16*)emb->ptr; P.ids = s.tokens; }
+        else P.src = (const f16*)s.input;
+        P.ln_w = (const f16*)ln0_w->ptr; P.ln_b = (const f16*)ln0_b->ptr; P.eps = 1.0e-5f;
         P.d = D; P.nmix = 0; P.ln_out = (f16*)s.x;
-        ln_mix(q, P, T);
+        LN(P, T);
     }
     for (uint32_t li = 0; li < d.num_layer; ++li) {
         const wrk_v7_layer_desc& L = layers[li];
@@ -265,7 +388,7 @@ int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_
             void* outs[6] = {s.rx, s.wx, s.kx, s.vx, s.ax, s.gx};
             for (int i = 0; i < 6; ++i) { P.mix[i] = (const f16*)mx[i]->ptr; P.out[i] = (f16*)outs[i]; }
             P.state_row = lst; P.state_stride = (size_t)(S + 2) * D; P.cursors = s.cursors;
-            ln_mix(q, P, T);
+            LN(P, T);
         }
         {   // K1
             MatJob jobs[7] = {job(L.w_r, vec(s.rx), vec(s.r), WRK_ACT_NONE), job(L.w_k, vec(s.kx), vec(s.k), WRK_ACT_NONE),
@@ -290,8 +413,7 @@ int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_
             P.r = (const f16*)s.r; P.k = (const f16*)s.k; P.v = (const f16*)s.v;
             P.v_first = (f16*)s.att_v0; P.out = (f16*)s.att_x;
             P.state = lst; P.cursors = s.cursors; P.gn_eps = 64.0e-5f; P.l2_eps = 1.0e-12f;
-            const size_t smem = (size_t)(d.lora_w + d.lora_a + d.lora_g + d.lora_v) * 4;
-            head_kernel<<<dim3(H, T), 256, smem, q>>>(P);
+            head_kernel<<<dim3(H, T), 256, 0, q>>>(P);
         }
         {   // K3: x += W_o . att_x
             MatJob j = job(L.w_o, vec(s.att_x), vec(s.x), WRK_ACT_NONE);
@@ -303,7 +425,7 @@ int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_
             P.src = (const f16*)s.x; P.ln_w = (const f16*)L.ln2_w->ptr; P.ln_b = (const f16*)L.ln2_b->ptr; P.eps = 1.0e-5f;
             P.d = D; P.nmix = 1; P.mix[0] = (const f16*)L.ffn_x_k->ptr; P.out[0] = (f16*)s.ffn_kx;
             P.state_row = lst + (size_t)(S + 1) * D; P.state_stride = (size_t)(S + 2) * D; P.cursors = s.cursors;
-            ln_mix(q, P, T);
+            LN(P, T);
         }
         {   // K5
             MatJob j = job(L.ffn_w_k, vec(s.ffn_kx), vec(s.ffn_k, F), WRK_ACT_SQUARED_RELU);
@@ -317,15 +439,24 @@ int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_
         if ((li + 1) % d.rescale == 0) wrk::affine(q, vec(s.x), 0.5f, 0.0f);
     }
     if (NH > 0) {
-        // header: rows -> LN(ln_out) -> head matmul (f32 logits)
+        // header: rows -> LN(ln_out) -> head matmul (f32 logits) [+ arg-max partials in the same launch]
         LnMixParams P{};
         P.src = (const f16*)s.x; P.ids = identity_headers ? nullptr : s.headers;
         P.ln_w = (const f16*)ln_out_w->ptr; P.ln_b = (const f16*)ln_out_b->ptr; P.eps = 1.0e-5f;
         P.d = D; P.nmix = 0; P.ln_out = (f16*)s.head_x;
-        ln_mix(q, P, NH);
+        LN(P, NH);
         MatJob j = job(head, make_dense(s.head_x, WRK_F16, D, NH), make_dense(s.head_o, WRK_F32, V, NH), WRK_ACT_NONE);
+        uint32_t nwg = 0;
+        if (want_argmax) {
+            nwg = matvec_num_wg(&j, 1, ctx->num_cu, nullptr);
+            if ((size_t)nwg * NH > amax_cap) return wrk_fail(ctx, WRK_E_ARG, "arg-max scratch too small");
+            j.amax_val = amax_val; j.amax_idx = amax_idx;
+        }
         if (matvec(q, &j, 1, ctx->num_cu) != 0) return wrk_fail(ctx, WRK_E_ARG, "fused head rejected");
+        if (want_argmax)
+            argmax_finish(q, amax_val, amax_idx, nwg, NH, s.argmax, advance ? s.tokens : nullptr, history, advance ? s.counter : nullptr);
     }
+#undef LN
     WRK_LAUNCH_CHECK(ctx);
     return WRK_OK;
 }
