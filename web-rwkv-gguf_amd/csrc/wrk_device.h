@@ -60,10 +60,22 @@ __device__ __forceinline__ float act_apply(uint32_t act, float x) {
 __device__ __forceinline__ float wgsl_mix(float x, float y, float a) { return x * (1.0f - a) + y * a; }
 
 // ------------------------------------------------------------------ reductions
+// wave64 sum on the VALU only: 4 DPP steps reduce every 16-lane row (quad xor 1, quad xor 2, half mirror,
+// row mirror), then the 4 row sums are read through SGPRs.  No ds_bpermute, no LDS latency.  All 64 lanes
+// must be active (EXEC full); the result is uniform.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
-    return v;
+    v += dpp_f32<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_f32<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_f32<0x141>(v);     // row_half_mirror
+    v += dpp_f32<0x140>(v);     // row_mirror
+    const int b = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+    return (r0 + r1) + (r2 + r3);
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

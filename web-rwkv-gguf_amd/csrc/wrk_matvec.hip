@@ -31,8 +31,8 @@ size_t repack_row_bytes(uint32_t kind, uint32_t k) {
     switch (kind) {
         case WRK_MAT_F16: return align16((size_t)k * 2);
         case WRK_MAT_Q8_0: return align16((size_t)k + (size_t)(k / 32) * 2);
-        case WRK_MAT_Q4_K: return nb * 144;
-        case WRK_MAT_Q5_K: return nb * 176;
+        case WRK_MAT_Q4_K: return align16(nb * 148);   // quants 128 | d,dmin 4 | unpacked 6-bit scales/mins 16
+        case WRK_MAT_Q5_K: return align16(nb * 180);   // quants 128 | high bits 32 | d,dmin 4 | scales/mins 16
         case WRK_MAT_Q6_K: return align16(nb * 208 + nb * 2);
         default: return 0;
     }
@@ -50,6 +50,18 @@ size_t stored_bytes(uint32_t kind, uint32_t k, uint32_t m) {
         case WRK_MAT_INT8: return n + n / 128 * 4;
         case WRK_MAT_NF4: return n / 2 + n / 64 * 2;
         default: return 0;
+    }
+}
+
+// get_scale_min_k4 (gguf.rs:81-89) applied once at upload: 12 packed bytes -> 16 bytes laid out per 64-element
+// group j as [sc(2j), sc(2j+1), m(2j), m(2j+1)], so a lane fetches its two (scale, min) pairs with one dword load.
+static void unpack_scales_k4(const uint8_t* s, uint8_t* out) {
+    for (int j = 0; j < 8; ++j) {
+        uint8_t sc, m;
+        if (j < 4) { sc = s[j] & 63; m = s[j + 4] & 63; }
+        else { sc = (s[j + 4] & 0xF) | ((s[j - 4] >> 6) << 4); m = (s[j + 4] >> 4) | ((s[j] >> 6) << 4); }
+        out[(j >> 1) * 4 + (j & 1)] = sc;
+        out[(j >> 1) * 4 + 2 + (j & 1)] = m;
     }
 }
 
@@ -78,7 +90,8 @@ int repack_rows(uint32_t kind, uint32_t k, uint32_t m, const uint8_t* src, uint8
                 const uint8_t* s = src + (size_t)r * nb * 144;
                 for (size_t b = 0; b < nb; ++b) {
                     memcpy(d + b * 128, s + b * 144 + 16, 128);
-                    memcpy(d + nb * 128 + b * 16, s + b * 144, 16);
+                    memcpy(d + nb * 128 + b * 4, s + b * 144, 4);              // d, dmin
+                    unpack_scales_k4(s + b * 144 + 4, d + nb * 132 + b * 16);
                 }
                 break;
             }
@@ -87,7 +100,8 @@ int repack_rows(uint32_t kind, uint32_t k, uint32_t m, const uint8_t* src, uint8
                 for (size_t b = 0; b < nb; ++b) {
                     memcpy(d + b * 128, s + b * 176 + 48, 128);            // ql
                     memcpy(d + nb * 128 + b * 32, s + b * 176 + 16, 32);   // qh
-                    memcpy(d + nb * 160 + b * 16, s + b * 176, 16);        // d, dmin, scales
+                    memcpy(d + nb * 160 + b * 4, s + b * 176, 4);          // d, dmin
+                    unpack_scales_k4(s + b * 176 + 4, d + nb * 164 + b * 16);
                 }
                 break;
             }
@@ -108,12 +122,13 @@ int repack_rows(uint32_t kind, uint32_t k, uint32_t m, const uint8_t* src, uint8
 }
 
 // ------------------------------------------------------------------ device: code -> f16 helpers
-// bytes b0..b3 of `v` (each < 1024) -> two f16x2 holding (b0, b1) and (b2, b3) minus `bias`
-__device__ __forceinline__ void bytes_to_h2(uint32_t v, f16x2 biasv, f16x2& lo, f16x2& hi) {
-    const uint32_t p0 = __builtin_amdgcn_perm(0x64646464u, v, 0x04010400u);   // 0x6400|b0 , 0x6400|b1
-    const uint32_t p1 = __builtin_amdgcn_perm(0x64646464u, v, 0x04030402u);   // 0x6400|b2 , 0x6400|b3
-    lo = __builtin_bit_cast(f16x2, p0) - biasv;
-    hi = __builtin_bit_cast(f16x2, p1) - biasv;
+// An integer code c < 1024 placed in the low bits of an f16 lane IS the subnormal c * 2^-24 (subnormals are
+// linear in the mantissa), so a byte becomes an exact f16 with one byte-permute and no arithmetic; the 2^24
+// (or 2^20 when the code sits in the high nibble, i.e. is 16*q) is folded into the group scale.
+// bytes b0..b3 of `v` -> two f16x2 holding (b0, b1) and (b2, b3) as subnormals
+__device__ __forceinline__ void bytes_to_h2(uint32_t v, f16x2& lo, f16x2& hi) {
+    lo = __builtin_bit_cast(f16x2, __builtin_amdgcn_perm(0u, v, 0x0c010c00u));   // 0x00 b1 0x00 b0
+    hi = __builtin_bit_cast(f16x2, __builtin_amdgcn_perm(0u, v, 0x0c030c02u));   // 0x00 b3 0x00 b2
 }
 
 __device__ __forceinline__ f16x2 h2(float a) { f16x2 r = {(f16)a, (f16)a}; return r; }
@@ -134,41 +149,36 @@ __device__ __forceinline__ float dot16(const f16x2 (&q)[8], const f16* __restric
     return acc;
 }
 
-// get_scale_min_k4 (gguf.rs:81-89) on the 12 scale bytes held in three dwords
-__device__ __forceinline__ void scale_min_k4(uint32_t is, uint32_t s0, uint32_t s1, uint32_t s2, float& sc, float& mn) {
-    const uint32_t sh = (is & 3u) * 8u;
-    const uint32_t a = (s0 >> sh) & 0xffu, b = (s1 >> sh) & 0xffu, c = (s2 >> sh) & 0xffu;
-    uint32_t scv, mv;
-    if (is < 4u) { scv = a & 63u; mv = b & 63u; }
-    else { scv = (c & 0xfu) | ((a >> 6) << 4); mv = (c >> 4) | ((b >> 6) << 4); }
-    sc = (float)scv;
-    mn = (float)mv;
-}
-
 __device__ __forceinline__ float f16bits_to_f32(uint32_t bits) { return (float)__builtin_bit_cast(f16, (uint16_t)bits); }
 
-// One decoded 16-element group: codes as f16 pairs plus the affine (scale, minv) with
-//   contribution = scale * dot(q, x[xoff..xoff+16)) - minv * xsum[xoff/16]
+// One decoded 16-element group.  Codes are f16 subnormals (code * qinv); the weight of element e is
+//   w_e = scale * (code_e - off) - minv         (ggml: d*sc*q - dmin*m, or d*sc*(q6 - 32), or d*(i8))
+// so  sum_e w_e x_e = scale * (qmul * dot(q, x) - off * sum x) - minv * sum x     with qmul = 1 / qinv.
 struct Group {
     f16x2 q[8];
-    float scale, minv;
+    float scale, minv, off, qmul;
     uint32_t xoff;
 };
+
+// ROUND_F16: w_e <- f16(scale * (code_e - off) - minv), the exact value the reference stores after CPU dequant
+__device__ __forceinline__ void round_group(Group& g) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float a = ((float)g.q[i][0] * g.qmul - g.off) * g.scale - g.minv;
+        const float b = ((float)g.q[i][1] * g.qmul - g.off) * g.scale - g.minv;
+        g.q[i][0] = (f16)a;
+        g.q[i][1] = (f16)b;
+    }
+}
 
 template <bool R16>
 __device__ __forceinline__ float group_dot(Group& g, const f16* __restrict__ xs, const float* __restrict__ xsum) {
     if (R16) {
-        // weight_e = f16(scale * q_e - minv): the exact value the reference stores after CPU dequant
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float a = (float)g.q[i][0] * g.scale - g.minv;
-            const float b = (float)g.q[i][1] * g.scale - g.minv;
-            g.q[i][0] = (f16)a;
-            g.q[i][1] = (f16)b;
-        }
+        round_group(g);
         return dot16(g.q, xs + g.xoff);
     }
-    return g.scale * dot16(g.q, xs + g.xoff) - g.minv * xsum[g.xoff >> 4];
+    const float sx = xsum[g.xoff >> 4];
+    return g.scale * (g.qmul * dot16(g.q, xs + g.xoff) - g.off * sx) - g.minv * sx;
 }
 
 template <bool R16, int NB>
@@ -192,8 +202,8 @@ __device__ __forceinline__ void groups_accumulate(const Group& lo, const Group& 
 // current one is decoded, and so the first chunk is requested before the inputs are staged.
 struct Raw {
     u32x4 w;    // quant chunk
-    u32x4 a;    // Q4_K: header | Q5_K: high bits | Q6_K: high bits | Q8_0: a.x = d bits
-    u32x4 b;    // Q5_K: header | Q6_K: b.x = sc_lo | sc_hi << 8 | d bits << 16
+    u32x4 a;    // Q5_K / Q6_K: high bits | Q4_K: a.x = d,dmin  a.y = sc,sc,m,m of the chunk's group | Q8_0: a.x = d bits
+    u32x2 b;    // Q5_K: b.x = d,dmin  b.y = sc,sc,m,m | Q6_K: b.x = sc_lo | sc_hi << 8 | d bits << 16
 };
 
 template <int KIND>
@@ -207,10 +217,12 @@ __device__ __forceinline__ Raw load_raw(const uint8_t* __restrict__ row, uint32_
     r.w = __builtin_nontemporal_load((const u32x4*)(row + (size_t)c * 16));
     const uint32_t nb = k >> 8, b = c >> 3;
     if (KIND == WRK_MAT_Q4_K) {
-        r.a = *(const u32x4*)(row + (size_t)nb * 128 + (size_t)b * 16);
+        r.a.x = *(const uint32_t*)(row + (size_t)nb * 128 + (size_t)b * 4);
+        r.a.y = *(const uint32_t*)(row + (size_t)nb * 132 + (size_t)b * 16 + ((c & 7u) >> 1) * 4);
     } else if (KIND == WRK_MAT_Q5_K) {
         r.a = *(const u32x4*)(row + (size_t)nb * 128 + (size_t)b * 32 + (c & 1u) * 16);
-        r.b = *(const u32x4*)(row + (size_t)nb * 160 + (size_t)b * 16);
+        r.b.x = *(const uint32_t*)(row + (size_t)nb * 160 + (size_t)b * 4);
+        r.b.y = *(const uint32_t*)(row + (size_t)nb * 164 + (size_t)b * 16 + ((c & 7u) >> 1) * 4);
     } else if (KIND == WRK_MAT_Q6_K) {
         const uint32_t sub = c & 7u, n128 = sub >> 2, part = (sub >> 1) & 1u, l0 = (sub & 1u) * 16u;
         r.a = *(const u32x4*)(row + (size_t)nb * 128 + (size_t)b * 64 + n128 * 32 + l0);
@@ -223,11 +235,93 @@ __device__ __forceinline__ Raw load_raw(const uint8_t* __restrict__ row, uint32_
     return r;
 }
 
+// decode one chunk into one or two 16-element groups (not used for F16)
+template <int KIND>
+__device__ __forceinline__ void decode_raw(const Raw& r, uint32_t c, Group& lo, Group& hi) {
+    const u32x4 w = r.w;
+    constexpr float Q24 = 16777216.0f, Q20 = 1048576.0f;       // 2^24, 2^20
+    if (KIND == WRK_MAT_Q8_0) {
+        bytes_to_h2(w.x ^ 0x80808080u, lo.q[0], lo.q[1]);        // u = int8 + 128
+        bytes_to_h2(w.y ^ 0x80808080u, lo.q[2], lo.q[3]);
+        bytes_to_h2(w.z ^ 0x80808080u, lo.q[4], lo.q[5]);
+        bytes_to_h2(w.w ^ 0x80808080u, lo.q[6], lo.q[7]);
+        lo.scale = f16bits_to_f32(r.a.x); lo.minv = 0.0f; lo.off = 128.0f; lo.qmul = Q24; lo.xoff = c * 16;
+        return;
+    }
+    const uint32_t b = c >> 3, sub = c & 7u;
+    if (KIND == WRK_MAT_Q6_K) {
+        const uint32_t n128 = sub >> 2, part = (sub >> 1) & 1u, l0 = (sub & 1u) * 16u;
+        const u32x4 qh = r.a;
+        const float sc_lo = (float)(int8_t)(r.b.x & 0xffu), sc_hi = (float)(int8_t)((r.b.x >> 8) & 0xffu);
+        const float d = f16bits_to_f32(r.b.x >> 16);
+        const uint32_t s_lo = part * 2, s_hi = s_lo + 4;
+#define Q6LO(W, H) (((W) & 0x0f0f0f0fu) | ((((H) >> s_lo) & 0x03030303u) << 4))
+#define Q6HI(W, H) ((((W) >> 4) & 0x0f0f0f0fu) | ((((H) >> s_hi) & 0x03030303u) << 4))
+        bytes_to_h2(Q6LO(w.x, qh.x), lo.q[0], lo.q[1]);
+        bytes_to_h2(Q6LO(w.y, qh.y), lo.q[2], lo.q[3]);
+        bytes_to_h2(Q6LO(w.z, qh.z), lo.q[4], lo.q[5]);
+        bytes_to_h2(Q6LO(w.w, qh.w), lo.q[6], lo.q[7]);
+        bytes_to_h2(Q6HI(w.x, qh.x), hi.q[0], hi.q[1]);
+        bytes_to_h2(Q6HI(w.y, qh.y), hi.q[2], hi.q[3]);
+        bytes_to_h2(Q6HI(w.z, qh.z), hi.q[4], hi.q[5]);
+        bytes_to_h2(Q6HI(w.w, qh.w), hi.q[6], hi.q[7]);
+#undef Q6LO
+#undef Q6HI
+        lo.scale = d * sc_lo; lo.minv = 0.0f; lo.off = 32.0f; lo.qmul = Q24; lo.xoff = b * 256 + n128 * 128 + part * 32 + l0;
+        hi.scale = d * sc_hi; hi.minv = 0.0f; hi.off = 32.0f; hi.qmul = Q24; hi.xoff = lo.xoff + 64;
+        return;
+    }
+    // Q4_K / Q5_K: d, dmin and the pre-unpacked (sc, sc', m, m') bytes of this chunk's 64-element group
+    const uint32_t j = sub >> 1, h = sub & 1u;
+    const uint32_t dd = KIND == WRK_MAT_Q4_K ? r.a.x : r.b.x, sm = KIND == WRK_MAT_Q4_K ? r.a.y : r.b.y;
+    const float d = f16bits_to_f32(dd & 0xffffu), dmin = f16bits_to_f32(dd >> 16);
+    const float sc0 = (float)(sm & 0xffu), sc1 = (float)((sm >> 8) & 0xffu), m0 = (float)((sm >> 16) & 0xffu), m1 = (float)(sm >> 24);
+    if (KIND == WRK_MAT_Q4_K) {
+        bytes_to_h2(w.x & 0x0f0f0f0fu, lo.q[0], lo.q[1]);
+        bytes_to_h2(w.y & 0x0f0f0f0fu, lo.q[2], lo.q[3]);
+        bytes_to_h2(w.z & 0x0f0f0f0fu, lo.q[4], lo.q[5]);
+        bytes_to_h2(w.w & 0x0f0f0f0fu, lo.q[6], lo.q[7]);
+        bytes_to_h2(w.x & 0xf0f0f0f0u, hi.q[0], hi.q[1]);        // 16 * q, the 1/16 lives in qmul
+        bytes_to_h2(w.y & 0xf0f0f0f0u, hi.q[2], hi.q[3]);
+        bytes_to_h2(w.z & 0xf0f0f0f0u, hi.q[4], hi.q[5]);
+        bytes_to_h2(w.w & 0xf0f0f0f0u, hi.q[6], hi.q[7]);
+        hi.qmul = Q20;
+    } else {
+        const u32x4 qh = r.a;
+        const uint32_t s0 = 2 * j, s1 = 2 * j + 1;
+#define Q5LO(W, H) (((W) & 0x0f0f0f0fu) | ((((H) >> s0) & 0x01010101u) << 4))
+#define Q5HI(W, H) ((((W) >> 4) & 0x0f0f0f0fu) | ((((H) >> s1) & 0x01010101u) << 4))
+        bytes_to_h2(Q5LO(w.x, qh.x), lo.q[0], lo.q[1]);
+        bytes_to_h2(Q5LO(w.y, qh.y), lo.q[2], lo.q[3]);
+        bytes_to_h2(Q5LO(w.z, qh.z), lo.q[4], lo.q[5]);
+        bytes_to_h2(Q5LO(w.w, qh.w), lo.q[6], lo.q[7]);
+        bytes_to_h2(Q5HI(w.x, qh.x), hi.q[0], hi.q[1]);
+        bytes_to_h2(Q5HI(w.y, qh.y), hi.q[2], hi.q[3]);
+        bytes_to_h2(Q5HI(w.z, qh.z), hi.q[4], hi.q[5]);
+        bytes_to_h2(Q5HI(w.w, qh.w), hi.q[6], hi.q[7]);
+#undef Q5LO
+#undef Q5HI
+        hi.qmul = Q24;
+    }
+    lo.scale = d * sc0; lo.minv = dmin * m0; lo.off = 0.0f; lo.qmul = Q24; lo.xoff = b * 256 + j * 64 + h * 16;
+    hi.scale = d * sc1; hi.minv = dmin * m1; hi.off = 0.0f; hi.xoff = lo.xoff + 32;
+}
+
+// element offsets of the (up to two) 16-element input groups that chunk c of a row multiplies
+template <int KIND>
+__device__ __forceinline__ void chunk_xoff(uint32_t c, uint32_t& lo, uint32_t& hi) {
+    if (KIND == WRK_MAT_F16) { lo = c * 8; hi = lo; return; }
+    if (KIND == WRK_MAT_Q8_0) { lo = c * 16; hi = lo; return; }
+    const uint32_t b = c >> 3, sub = c & 7u;
+    if (KIND == WRK_MAT_Q6_K) { lo = b * 256 + (sub >> 2) * 128 + ((sub >> 1) & 1u) * 32 + (sub & 1u) * 16; hi = lo + 64; return; }
+    lo = b * 256 + (sub >> 1) * 64 + (sub & 1u) * 16;
+    hi = lo + 32;
+}
+
 template <int KIND, bool R16, int NB>
 __device__ __forceinline__ void dot_raw(const Raw& r, uint32_t c, const f16* xs, const float* xsum, uint32_t kpad, float (&acc)[NB]) {
-    const u32x4 w = r.w;
     if (KIND == WRK_MAT_F16) {
-        const f16x8 wv = __builtin_bit_cast(f16x8, w);
+        const f16x8 wv = __builtin_bit_cast(f16x8, r.w);
 #pragma unroll
         for (int n = 0; n < NB; ++n) {
             const f16x8 x = *(const f16x8*)(xs + (size_t)n * kpad + c * 8);
@@ -241,78 +335,83 @@ __device__ __forceinline__ void dot_raw(const Raw& r, uint32_t c, const f16* xs,
         return;
     }
     Group lo, hi;
-    if (KIND == WRK_MAT_Q8_0) {
-        const f16x2 bias = h2(1152.0f);    // 1024 + 128: int8 = (byte ^ 0x80) - 128
-        bytes_to_h2(w.x ^ 0x80808080u, bias, lo.q[0], lo.q[1]);
-        bytes_to_h2(w.y ^ 0x80808080u, bias, lo.q[2], lo.q[3]);
-        bytes_to_h2(w.z ^ 0x80808080u, bias, lo.q[4], lo.q[5]);
-        bytes_to_h2(w.w ^ 0x80808080u, bias, lo.q[6], lo.q[7]);
-        lo.scale = f16bits_to_f32(r.a.x); lo.minv = 0.0f; lo.xoff = c * 16;
-        hi = lo;
-        groups_accumulate<R16, NB>(lo, hi, false, xs, xsum, kpad, acc);
-        return;
+    decode_raw<KIND>(r, c, lo, hi);
+    groups_accumulate<R16, NB>(lo, hi, KIND != WRK_MAT_Q8_0, xs, xsum, kpad, acc);
+}
+
+// ------------------------------------------------------------------ register-resident inputs (single input vector)
+// With one row per wave and lane L owning chunks L, L+64, ... of EVERY row, the inputs a lane multiplies are
+// the same for all rows: they are loaded once into registers (no LDS staging, no barrier, no bank conflicts).
+struct XRegs {
+    f16x8 v[4];     // lo group = v[0..1], hi group = v[2..3]   (F16: v[0] only; Q8_0: v[0..1])
+    float s[2];     // sum of the 16 inputs of each group (the K-quant "min" term)
+};
+
+__device__ __forceinline__ float sum8(f16x8 a) {
+    const f16x2 one = {(f16)1.0f, (f16)1.0f};
+    float s = 0.0f;
+    s = __builtin_amdgcn_fdot2(__builtin_shufflevector(a, a, 0, 1), one, s, false);
+    s = __builtin_amdgcn_fdot2(__builtin_shufflevector(a, a, 2, 3), one, s, false);
+    s = __builtin_amdgcn_fdot2(__builtin_shufflevector(a, a, 4, 5), one, s, false);
+    s = __builtin_amdgcn_fdot2(__builtin_shufflevector(a, a, 6, 7), one, s, false);
+    return s;
+}
+
+template <int KIND>
+__device__ __forceinline__ XRegs load_x(const f16* __restrict__ x, uint32_t c, bool valid) {
+    XRegs r;
+    const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    r.v[0] = r.v[1] = r.v[2] = r.v[3] = z;
+    r.s[0] = r.s[1] = 0.0f;
+    if (!valid) return r;
+    uint32_t lo, hi;
+    chunk_xoff<KIND>(c, lo, hi);
+    r.v[0] = *(const f16x8*)(x + lo);
+    if (KIND != WRK_MAT_F16) r.v[1] = *(const f16x8*)(x + lo + 8);
+    if (KIND != WRK_MAT_F16 && KIND != WRK_MAT_Q8_0) { r.v[2] = *(const f16x8*)(x + hi); r.v[3] = *(const f16x8*)(x + hi + 8); }
+    if (KIND != WRK_MAT_F16) r.s[0] = sum8(r.v[0]) + sum8(r.v[1]);
+    if (KIND != WRK_MAT_F16 && KIND != WRK_MAT_Q8_0) r.s[1] = sum8(r.v[2]) + sum8(r.v[3]);
+    return r;
+}
+
+__device__ __forceinline__ float dot16r(const f16x2 (&q)[8], const f16x8 xa, const f16x8 xb) {
+    float acc = 0.0f;
+    acc = __builtin_amdgcn_fdot2(q[0], __builtin_shufflevector(xa, xa, 0, 1), acc, false);
+    acc = __builtin_amdgcn_fdot2(q[1], __builtin_shufflevector(xa, xa, 2, 3), acc, false);
+    acc = __builtin_amdgcn_fdot2(q[2], __builtin_shufflevector(xa, xa, 4, 5), acc, false);
+    acc = __builtin_amdgcn_fdot2(q[3], __builtin_shufflevector(xa, xa, 6, 7), acc, false);
+    acc = __builtin_amdgcn_fdot2(q[4], __builtin_shufflevector(xb, xb, 0, 1), acc, false);
+    acc = __builtin_amdgcn_fdot2(q[5], __builtin_shufflevector(xb, xb, 2, 3), acc, false);
+    acc = __builtin_amdgcn_fdot2(q[6], __builtin_shufflevector(xb, xb, 4, 5), acc, false);
+    acc = __builtin_amdgcn_fdot2(q[7], __builtin_shufflevector(xb, xb, 6, 7), acc, false);
+    return acc;
+}
+
+template <bool R16>
+__device__ __forceinline__ float group_dot_r(Group& g, const f16x8 xa, const f16x8 xb, float xs16) {
+    if (R16) {
+        round_group(g);
+        return dot16r(g.q, xa, xb);
     }
-    const uint32_t b = c >> 3, sub = c & 7u;
-    if (KIND == WRK_MAT_Q6_K) {
-        const uint32_t n128 = sub >> 2, part = (sub >> 1) & 1u, l0 = (sub & 1u) * 16u;
-        const u32x4 qh = r.a;
-        const float sc_lo = (float)(int8_t)(r.b.x & 0xffu), sc_hi = (float)(int8_t)((r.b.x >> 8) & 0xffu);
-        const float d = f16bits_to_f32(r.b.x >> 16);
-        const uint32_t s_lo = part * 2, s_hi = s_lo + 4;
-        const f16x2 bias = h2(1056.0f);    // 1024 + 32: q6 = code - 32, exact in f16
-#define Q6LO(W, H) (((W) & 0x0f0f0f0fu) | ((((H) >> s_lo) & 0x03030303u) << 4))
-#define Q6HI(W, H) ((((W) >> 4) & 0x0f0f0f0fu) | ((((H) >> s_hi) & 0x03030303u) << 4))
-        bytes_to_h2(Q6LO(w.x, qh.x), bias, lo.q[0], lo.q[1]);
-        bytes_to_h2(Q6LO(w.y, qh.y), bias, lo.q[2], lo.q[3]);
-        bytes_to_h2(Q6LO(w.z, qh.z), bias, lo.q[4], lo.q[5]);
-        bytes_to_h2(Q6LO(w.w, qh.w), bias, lo.q[6], lo.q[7]);
-        bytes_to_h2(Q6HI(w.x, qh.x), bias, hi.q[0], hi.q[1]);
-        bytes_to_h2(Q6HI(w.y, qh.y), bias, hi.q[2], hi.q[3]);
-        bytes_to_h2(Q6HI(w.z, qh.z), bias, hi.q[4], hi.q[5]);
-        bytes_to_h2(Q6HI(w.w, qh.w), bias, hi.q[6], hi.q[7]);
-#undef Q6LO
-#undef Q6HI
-        lo.scale = d * sc_lo; lo.minv = 0.0f; lo.xoff = b * 256 + n128 * 128 + part * 32 + l0;
-        hi.scale = d * sc_hi; hi.minv = 0.0f; hi.xoff = lo.xoff + 64;
-        groups_accumulate<R16, NB>(lo, hi, true, xs, xsum, kpad, acc);
-        return;
+    return g.scale * (g.qmul * dot16r(g.q, xa, xb) - g.off * xs16) - g.minv * xs16;
+}
+
+template <int KIND, bool R16>
+__device__ __forceinline__ float dot_raw_reg(const Raw& r, uint32_t c, const XRegs& x) {
+    if (KIND == WRK_MAT_F16) {
+        const f16x8 wv = __builtin_bit_cast(f16x8, r.w);
+        float a = 0.0f;
+        a = __builtin_amdgcn_fdot2(__builtin_shufflevector(wv, wv, 0, 1), __builtin_shufflevector(x.v[0], x.v[0], 0, 1), a, false);
+        a = __builtin_amdgcn_fdot2(__builtin_shufflevector(wv, wv, 2, 3), __builtin_shufflevector(x.v[0], x.v[0], 2, 3), a, false);
+        a = __builtin_amdgcn_fdot2(__builtin_shufflevector(wv, wv, 4, 5), __builtin_shufflevector(x.v[0], x.v[0], 4, 5), a, false);
+        a = __builtin_amdgcn_fdot2(__builtin_shufflevector(wv, wv, 6, 7), __builtin_shufflevector(x.v[0], x.v[0], 6, 7), a, false);
+        return a;
     }
-    // Q4_K / Q5_K share the d/dmin/6-bit scale header
-    const uint32_t j = sub >> 1, h = sub & 1u;
-    const u32x4 hd = KIND == WRK_MAT_Q4_K ? r.a : r.b;
-    const float d = f16bits_to_f32(hd.x & 0xffffu), dmin = f16bits_to_f32(hd.x >> 16);
-    float sc0, m0, sc1, m1;
-    scale_min_k4(2 * j, hd.y, hd.z, hd.w, sc0, m0);
-    scale_min_k4(2 * j + 1, hd.y, hd.z, hd.w, sc1, m1);
-    const f16x2 bias = h2(1024.0f);
-    if (KIND == WRK_MAT_Q4_K) {
-        bytes_to_h2(w.x & 0x0f0f0f0fu, bias, lo.q[0], lo.q[1]);
-        bytes_to_h2(w.y & 0x0f0f0f0fu, bias, lo.q[2], lo.q[3]);
-        bytes_to_h2(w.z & 0x0f0f0f0fu, bias, lo.q[4], lo.q[5]);
-        bytes_to_h2(w.w & 0x0f0f0f0fu, bias, lo.q[6], lo.q[7]);
-        bytes_to_h2((w.x >> 4) & 0x0f0f0f0fu, bias, hi.q[0], hi.q[1]);
-        bytes_to_h2((w.y >> 4) & 0x0f0f0f0fu, bias, hi.q[2], hi.q[3]);
-        bytes_to_h2((w.z >> 4) & 0x0f0f0f0fu, bias, hi.q[4], hi.q[5]);
-        bytes_to_h2((w.w >> 4) & 0x0f0f0f0fu, bias, hi.q[6], hi.q[7]);
-    } else {
-        const u32x4 qh = r.a;
-        const uint32_t s0 = 2 * j, s1 = 2 * j + 1;
-#define Q5LO(W, H) (((W) & 0x0f0f0f0fu) | ((((H) >> s0) & 0x01010101u) << 4))
-#define Q5HI(W, H) ((((W) >> 4) & 0x0f0f0f0fu) | ((((H) >> s1) & 0x01010101u) << 4))
-        bytes_to_h2(Q5LO(w.x, qh.x), bias, lo.q[0], lo.q[1]);
-        bytes_to_h2(Q5LO(w.y, qh.y), bias, lo.q[2], lo.q[3]);
-        bytes_to_h2(Q5LO(w.z, qh.z), bias, lo.q[4], lo.q[5]);
-        bytes_to_h2(Q5LO(w.w, qh.w), bias, lo.q[6], lo.q[7]);
-        bytes_to_h2(Q5HI(w.x, qh.x), bias, hi.q[0], hi.q[1]);
-        bytes_to_h2(Q5HI(w.y, qh.y), bias, hi.q[2], hi.q[3]);
-        bytes_to_h2(Q5HI(w.z, qh.z), bias, hi.q[4], hi.q[5]);
-        bytes_to_h2(Q5HI(w.w, qh.w), bias, hi.q[6], hi.q[7]);
-#undef Q5LO
-#undef Q5HI
-    }
-    lo.scale = d * sc0; lo.minv = dmin * m0; lo.xoff = b * 256 + j * 64 + h * 16;
-    hi.scale = d * sc1; hi.minv = dmin * m1; hi.xoff = lo.xoff + 32;
-    groups_accumulate<R16, NB>(lo, hi, true, xs, xsum, kpad, acc);
+    Group lo, hi;
+    decode_raw<KIND>(r, c, lo, hi);
+    float a = group_dot_r<R16>(lo, x.v[0], x.v[1], x.s[0]);
+    if (KIND != WRK_MAT_Q8_0) a += group_dot_r<R16>(hi, x.v[2], x.v[3], x.s[1]);
+    return a;
 }
 
 // ------------------------------------------------------------------ the kernel
@@ -345,15 +444,22 @@ __device__ __forceinline__ void matvec_body(const JobDev& J, unsigned char* smem
     const uint32_t r0 = (blockIdx.x - J.wg_begin) * J.rows_per_wg;
     const uint32_t r1 = min(r0 + J.rows_per_wg, J.m);
 
-    // work items of this wave: (row, chunk iteration); item it -> row r0 + wave + 4 * (it / iters)
+    // rows of this wave: r0 + wave + 4 * ri, processed RB at a time so that RB independent 16-byte loads per
+    // lane (RB KiB per wave) are in flight together; chunk c of a row = lane + 64 * ci
+    constexpr int RB = NB == 1 ? 4 : (NB == 2 ? 2 : 1);
     const uint32_t nch = num_chunks<KIND>(K, kpad);
     const uint32_t iters = (nch + 63) >> 6;
     const uint32_t nrows = r0 + wave < r1 ? (r1 - r0 - wave + 3) >> 2 : 0;
-    const uint32_t nitems = nrows * iters;
 
-    // request the first chunk before touching the inputs: weights do not depend on activations
-    Raw cur{};
-    if (nitems > 0 && lane < nch) cur = load_raw<KIND>(J.w + (size_t)(r0 + wave) * J.row_bytes, K, lane);
+    Raw raw[RB];
+    auto issue = [&](uint32_t ri0, uint32_t ci) {
+        const uint32_t c = lane + 64 * ci;
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+            if (ri0 + rb < nrows && c < nch) raw[rb] = load_raw<KIND>(J.w + (size_t)(r0 + wave + 4 * (ri0 + rb)) * J.row_bytes, K, c);
+    };
+    // request the first chunks before touching the inputs: weights do not depend on activations
+    issue(0, 0);
 
     // stage inputs (f16) and their per-16 sums
 #pragma unroll
@@ -389,26 +495,32 @@ __device__ __forceinline__ void matvec_body(const JobDev& J, unsigned char* smem
     }
     __syncthreads();
 
-    float acc[NB];
     float best_v[NB];
     uint32_t best_i[NB];
 #pragma unroll
-    for (int n = 0; n < NB; ++n) { acc[n] = 0.0f; best_v[n] = -3.0e38f; best_i[n] = 0xffffffffu; }
-    for (uint32_t it = 0; it < nitems; ++it) {
-        const uint32_t ri = it / iters, ci = it - ri * iters;
-        const uint32_t r = r0 + wave + 4 * ri, c = lane + 64 * ci;
-        // prefetch the next item
-        Raw nxt{};
-        if (it + 1 < nitems) {
-            const uint32_t it2 = it + 1, ri2 = it2 / iters, ci2 = it2 - ri2 * iters, c2 = lane + 64 * ci2;
-            if (c2 < nch) nxt = load_raw<KIND>(J.w + (size_t)(r0 + wave + 4 * ri2) * J.row_bytes, K, c2);
+    for (int n = 0; n < NB; ++n) { best_v[n] = -3.0e38f; best_i[n] = 0xffffffffu; }
+    for (uint32_t ri0 = 0; ri0 < nrows; ri0 += RB) {
+        float acc[RB][NB];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int n = 0; n < NB; ++n) acc[rb][n] = 0.0f;
+        for (uint32_t ci = 0; ci < iters; ++ci) {
+            if (ri0 != 0 || ci != 0) issue(ri0, ci);
+            const uint32_t c = lane + 64 * ci;
+            if (c < nch) {
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb)
+                    if (ri0 + rb < nrows) dot_raw<KIND, R16, NB>(raw[rb], c, xs, xsum, kpad, acc[rb]);
+            }
         }
-        if (c < nch) dot_raw<KIND, R16, NB>(cur, c, xs, xsum, kpad, acc);
-        if (ci + 1 == iters) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            if (ri0 + rb >= nrows) break;
+            const uint32_t r = r0 + wave + 4 * (ri0 + rb);
 #pragma unroll
             for (int n = 0; n < NB; ++n) {
-                const float v = wave_sum(acc[n]);
-                acc[n] = 0.0f;
+                const float v = wave_sum(acc[rb][n]);
                 const uint32_t tk = tok0 + n;
                 if (lane == 0 && tk < ntok) {
                     const uint32_t t = tk % J.in.shape[1], b = tk / J.in.shape[1];
@@ -419,7 +531,6 @@ __device__ __forceinline__ void matvec_body(const JobDev& J, unsigned char* smem
                 }
             }
         }
-        cur = nxt;
     }
     if (J.amax_val) {       // fused greedy sampling, stage 1: per-workgroup (max, first index) of the rows it produced
         __syncthreads();
@@ -445,7 +556,116 @@ __device__ __forceinline__ void matvec_body(const JobDev& J, unsigned char* smem
     }
 }
 
-template <int NB>
+// Decode body: ONE input vector, inputs in registers, RB rows in flight per wave.  No input staging in LDS.
+//   KS == 1: a wave owns rows (r0 + wave + 4*i) and walks XI chunk iterations per row (K <= 2048*XI for block kinds)
+//   KS == 4: the 4 waves of the workgroup split K (wave w owns chunks 64w..64w+63, XI == 1) and every wave walks
+//            ALL rows of the workgroup; the four partial sums per row meet in LDS once, at the end.
+template <int KIND, bool R16, int XI, int KS>
+__device__ __forceinline__ void matvec_body_reg(const JobDev& J, unsigned char* smem) {
+    constexpr int RB = KIND == WRK_MAT_F16 ? 4 : 2;
+    static_assert(KS == 1 || XI == 1, "K-split uses one chunk iteration per wave");
+    const uint32_t K = J.k;
+    const uint32_t kpad = (K + 15u) & ~15u;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t r0 = (blockIdx.x - J.wg_begin) * J.rows_per_wg;
+    const uint32_t r1 = min(r0 + J.rows_per_wg, J.m);
+    const uint32_t nch = num_chunks<KIND>(K, kpad);
+    const uint32_t nrows = KS == 1 ? (r0 + wave < r1 ? (r1 - r0 - wave + 3) >> 2 : 0) : (r1 - r0);
+    const uint32_t cbase = KS == 1 ? lane : lane + 64 * wave;
+    auto row_of = [&](uint32_t ri) { return KS == 1 ? r0 + wave + 4 * ri : r0 + ri; };
+
+    Raw raw[RB][XI];
+    auto issue = [&](uint32_t ri0) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int ci = 0; ci < XI; ++ci) {
+                const uint32_t c = cbase + 64 * ci;
+                if (ri0 + rb < nrows && c < nch) raw[rb][ci] = load_raw<KIND>(J.w + (size_t)row_of(ri0 + rb) * J.row_bytes, K, c);
+            }
+    };
+    issue(0);       // weights first: they do not depend on the activations
+    const f16* xin = (const f16*)J.in.p + dt_index(J.in, 0, 0, 0);
+    XRegs x[XI];
+#pragma unroll
+    for (int ci = 0; ci < XI; ++ci) x[ci] = load_x<KIND>(xin, cbase + 64 * ci, cbase + 64 * ci < nch);
+
+    float* part = (float*)smem;                 // KS == 4: [32 rows][4 waves]
+    float best_v = -3.0e38f;
+    uint32_t best_i = 0xffffffffu;
+    auto finish = [&](uint32_t r, float v) {    // activation, fused residual, store, running arg-max
+        float o = act_apply(J.act, v);
+        if (J.has_res) o = dt_round(J.out, o) + dt_load(J.res, dt_index(J.res, r, 0, 0));
+        dt_store(J.out, dt_index(J.out, r, 0, 0), o);
+        if (o > best_v || (o == best_v && r < best_i)) { best_v = o; best_i = r; }
+    };
+    for (uint32_t ri0 = 0; ri0 < nrows; ri0 += RB) {
+        if (ri0 != 0) issue(ri0);
+        float acc[RB];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            acc[rb] = 0.0f;
+#pragma unroll
+            for (int ci = 0; ci < XI; ++ci) {
+                const uint32_t c = cbase + 64 * ci;
+                if (ri0 + rb < nrows && c < nch) acc[rb] += dot_raw_reg<KIND, R16>(raw[rb][ci], c, x[ci]);
+            }
+        }
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            if (ri0 + rb >= nrows) break;
+            const float v = wave_sum(acc[rb]);
+            if (lane == 0) {
+                if (KS == 1) finish(row_of(ri0 + rb), v);
+                else part[(ri0 + rb) * 4 + wave] = v;
+            }
+        }
+    }
+    if (KS == 4) {
+        __syncthreads();
+        if (tid < nrows) finish(r0 + tid, (part[tid * 4] + part[tid * 4 + 1]) + (part[tid * 4 + 2] + part[tid * 4 + 3]));
+    }
+    if (J.amax_val) {       // fused greedy sampling, stage 1 (uniform branch: every wave of the launch takes it)
+        float* sv = (float*)(smem + 512);
+        uint32_t* si = (uint32_t*)(smem + 528);
+        if (KS == 4) {      // candidates sit in lanes 0..nrows-1 of wave 0
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(best_v, o, WAVE);
+                const uint32_t oi = __shfl_xor(best_i, o, WAVE);
+                if (ov > best_v || (ov == best_v && oi < best_i)) { best_v = ov; best_i = oi; }
+            }
+        }
+        if (lane == 0) { sv[wave] = best_v; si[wave] = best_i; }
+        __syncthreads();
+        if (tid == 0) {
+            float bv = sv[0];
+            uint32_t bi = si[0];
+            for (int w = 1; w < 4; ++w)
+                if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
+            J.amax_val[blockIdx.x - J.wg_begin] = bv;
+            J.amax_idx[blockIdx.x - J.wg_begin] = bi;
+        }
+    }
+}
+
+template <int KA, int KB, bool R16, int XI, int KS>
+__global__ void __launch_bounds__(256) matvec_reg_kernel(const MatvecParams P) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[576];
+    int ji = 0;
+#pragma unroll
+    for (int q = 1; q < MAX_JOBS; ++q)
+        if (q < P.njobs && blockIdx.x >= P.jobs[q].wg_begin) ji = q;
+    const JobDev& J = P.jobs[ji];
+    if (KA == KB || J.kind == (uint32_t)KA) matvec_body_reg<KA, (KA != WRK_MAT_F16) && R16, XI, KS>(J, smem);
+    else matvec_body_reg<KB, (KB != WRK_MAT_F16) && R16, (KB == WRK_MAT_F16 ? 4 * XI : XI), 1>(J, smem);
+}
+
+// One kernel per (inputs-per-pass, kind pair, rounding mode): register allocation is the maximum over
+// the code paths a kernel contains, so a launch only carries the decoders its jobs need (a quantised
+// kind plus F16 for the LoRA matrices of the same launch).  KA == KB for single-kind launches;
+// KA == -1 is the catch-all used when one launch mixes more than two kinds.
+template <int NB, int KA, int KB, bool R16>
 __global__ void __launch_bounds__(256) matvec_kernel(const MatvecParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int ji = 0;
@@ -453,6 +673,11 @@ __global__ void __launch_bounds__(256) matvec_kernel(const MatvecParams P) {
     for (int q = 1; q < MAX_JOBS; ++q)
         if (q < P.njobs && blockIdx.x >= P.jobs[q].wg_begin) ji = q;
     const JobDev& J = P.jobs[ji];
+    if (KA >= 0) {
+        if (KA == KB || J.kind == (uint32_t)KA) matvec_body<KA, (KA != WRK_MAT_F16) && R16, NB>(J, smem);
+        else matvec_body<KB, (KB != WRK_MAT_F16) && R16, NB>(J, smem);
+        return;
+    }
     const bool r16w = (J.flags & WRK_MATRIX_ROUND_F16) != 0;
     switch (J.kind) {
         case WRK_MAT_Q4_K: if (r16w) matvec_body<WRK_MAT_Q4_K, true, NB>(J, smem); else matvec_body<WRK_MAT_Q4_K, false, NB>(J, smem); break;
@@ -463,12 +688,100 @@ __global__ void __launch_bounds__(256) matvec_kernel(const MatvecParams P) {
     }
 }
 
+typedef void (*matvec_fn)(const MatvecParams);
+
+template <int NB, int KA, int KB>
+static matvec_fn pick_r16(bool r16) {
+    return r16 ? (matvec_fn)matvec_kernel<NB, KA, KB, true> : (matvec_fn)matvec_kernel<NB, KA, KB, false>;
+}
+
+template <int NB>
+static matvec_fn pick_kernel(int ka, int kb, bool r16) {
+    // ka: the quantised kind of the launch (or F16 if none); kb: F16 when LoRA/F16 jobs ride along, else == ka
+#define PAIR(A)                                                                     \
+    if (ka == A) return kb == A ? pick_r16<NB, A, A>(r16) : pick_r16<NB, A, WRK_MAT_F16>(r16);
+    PAIR(WRK_MAT_Q4_K)
+    PAIR(WRK_MAT_Q5_K)
+    PAIR(WRK_MAT_Q6_K)
+    PAIR(WRK_MAT_Q8_0)
+#undef PAIR
+    if (ka == WRK_MAT_F16) return pick_r16<NB, WRK_MAT_F16, WRK_MAT_F16>(false);
+    return (matvec_fn)matvec_kernel<NB, -1, -1, false>;
+}
+
+template <int KA, int KB, int XI, int KS>
+static matvec_fn pick_reg_r16(bool r16) {
+    return r16 ? (matvec_fn)matvec_reg_kernel<KA, KB, true, XI, KS> : (matvec_fn)matvec_reg_kernel<KA, KB, false, XI, KS>;
+}
+
+template <int XI, int KS>
+static matvec_fn pick_reg_kernel(int ka, int kb, bool r16) {
+#define PAIR(A)                                                                     \
+    if (ka == A) return (kb == A || KS == 4) ? pick_reg_r16<A, A, XI, KS>(r16) : pick_reg_r16<A, WRK_MAT_F16, XI, 1>(r16);
+    PAIR(WRK_MAT_Q4_K)
+    PAIR(WRK_MAT_Q5_K)
+    PAIR(WRK_MAT_Q6_K)
+    PAIR(WRK_MAT_Q8_0)
+#undef PAIR
+    return nullptr;
+}
+
+// register-input decode kernel: one input vector, dense f16 input rows
+static matvec_fn pick_reg(const MatvecParams& P, int quant, bool has_f16, bool r16) {
+    uint32_t xi = 1;
+    for (int j = 0; j < P.njobs; ++j) {
+        const JobDev& J = P.jobs[j];
+        if (J.in.dtype != WRK_F16 || (J.k & 7u) || J.in.shape[1] * J.in.shape[2] != 1) return nullptr;
+        const size_t base = ((size_t)J.in.offset[2] * J.in.stride[1] + J.in.offset[1]) * J.in.stride[0] + J.in.offset[0];
+        if (base & 7u) return nullptr;
+        const uint32_t kpad = (J.k + 15u) & ~15u;
+        // chunk iterations per row, in units of the QUANTISED kind's count (F16 rows carry 4x the chunks per element)
+        uint32_t nch, need;
+        if (J.kind == WRK_MAT_F16) { nch = kpad >> 3; need = quant < 0 ? (nch + 63) / 64 : (nch + 255) / 256; }
+        else { nch = J.kind == WRK_MAT_Q8_0 ? (J.k >> 4) : (J.k >> 8) * 8; need = (nch + 63) / 64; }
+        xi = need > xi ? need : xi;
+    }
+    if (xi > 4) return nullptr;
+    if (quant < 0) {    // F16-only launch
+        if (xi == 1) return (matvec_fn)matvec_reg_kernel<WRK_MAT_F16, WRK_MAT_F16, false, 1, 1>;
+        if (xi == 2) return (matvec_fn)matvec_reg_kernel<WRK_MAT_F16, WRK_MAT_F16, false, 2, 1>;
+        return (matvec_fn)matvec_reg_kernel<WRK_MAT_F16, WRK_MAT_F16, false, 4, 1>;
+    }
+    const int kb = has_f16 ? WRK_MAT_F16 : quant;
+    if (xi == 1) return pick_reg_kernel<1, 1>(quant, kb, r16);
+    if (xi == 2) return pick_reg_kernel<2, 1>(quant, kb, r16);
+    if (has_f16) return nullptr;                    // K-split kernels are single-kind
+    for (int j = 0; j < P.njobs; ++j) if (P.jobs[j].rows_per_wg > 32) return nullptr;
+    return pick_reg_kernel<1, 4>(quant, quant, r16); // 2048 < K <= 8192 for the block kinds: split K over the 4 waves
+}
+
 template <int NB>
 static int launch_matvec(hipStream_t s, const MatvecParams& P, uint32_t total_wg, uint32_t tok_groups, size_t smem) {
-    if (smem > 64 * 1024) {
-        if (hipFuncSetAttribute((const void*)matvec_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -1;
+    // classify the kinds of this launch
+    int quant = -1, nquant = 0;
+    bool has_f16 = false, r16 = false, mixed_r16 = false;
+    for (int j = 0; j < P.njobs; ++j) {
+        const int k = (int)P.jobs[j].kind;
+        if (k == WRK_MAT_F16) { has_f16 = true; continue; }
+        const bool jr = (P.jobs[j].flags & WRK_MATRIX_ROUND_F16) != 0;
+        if (nquant == 0) { quant = k; r16 = jr; nquant = 1; }
+        else { if (k != quant) nquant = 2; if (jr != r16) mixed_r16 = true; }
     }
-    matvec_kernel<NB><<<dim3(total_wg, tok_groups), 256, smem, s>>>(P);
+    matvec_fn fn = nullptr;
+    if (NB == 1 && tok_groups == 1 && nquant <= 1 && !mixed_r16) {
+        fn = pick_reg(P, nquant ? quant : -1, has_f16, r16);
+        if (fn) {
+            hipLaunchKernelGGL(fn, dim3(total_wg, 1), dim3(256), 0, s, P);
+            return 0;
+        }
+    }
+    if (nquant >= 2 || mixed_r16) fn = (matvec_fn)matvec_kernel<NB, -1, -1, false>;
+    else if (nquant == 0) fn = pick_kernel<NB>(WRK_MAT_F16, WRK_MAT_F16, false);
+    else fn = pick_kernel<NB>(quant, has_f16 ? WRK_MAT_F16 : quant, r16);
+    if (smem > 64 * 1024) {
+        if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -1;
+    }
+    hipLaunchKernelGGL(fn, dim3(total_wg, tok_groups), dim3(256), smem, s, P);
     return 0;
 }
 
