@@ -28,6 +28,19 @@ sys.path.insert(0, os.path.join(ROOT, "web-rwkv-gguf_amd"))
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy rate ~6.3 TB/s
 
+
+def measured_traffic(model, batch, mode):
+    """HBM bytes per decode step from the committed PMC run of this same command
+    (profiles/r01_pmc_traffic.json, made by tools/pmc_summary.py from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+    passes; counters cannot be read from inside the process).  None when no matching profile exists."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if not (model == "1.5B" and batch == 1 and mode == 1 and os.path.exists(path)):
+        return None
+    try:
+        return int(json.load(open(path))["hbm_bytes_per_step"])
+    except Exception:
+        return None
+
 CONFIGS = {     # SURVEY section 8 table: L, D, F, V, lora w/a/v/g
     "tiny": (2, 256, 1024, 512, 32, 32, 32, 64),
     "0.1B": (12, 768, 3072, 65536, 64, 64, 32, 128),
@@ -159,6 +172,8 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import wrk
+    from wrk import replicas
+    group = replicas.ReplicaGroup(dist, device="cuda" if dist is not None else None)
     t0 = time.time()
     gg = make_model_gguf(args.model, seed=42 + rank)
     ctx = wrk.Context(local_rank)
@@ -173,7 +188,7 @@ def main():
         ctx.sync()
         if dist is not None:
             import torch
-            dist.barrier()
+            group.barrier()
             torch.cuda.synchronize()
 
     if args.warmup > 0:
@@ -184,12 +199,7 @@ def main():
     ctx.sync()
     wall_ms = (time.perf_counter() - w0) * 1e3
     barrier()
-    ms = max(dev_ms, 0.0)
-    if dist is not None:
-        import torch
-        t = torch.tensor([ms], device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        ms = float(t.item())
+    ms = group.max_over_ranks(max(dev_ms, 0.0))
 
     if rank == 0:
         ms_per_step = ms / args.steps
@@ -204,7 +214,7 @@ def main():
                                    f"{'fused kernels' if args.mode == 1 else 'one kernel per reference op'} under hipGraph",
                        "streams_per_gpu": B, "parallelism": f"replicas x{world}" if world > 1 else "single"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.model, B, args.mode),
                          "kernel": "one decode step = one hipGraph launch", "algorithmic_bytes_per_launch": token_bytes},
             "wall_ms_per_step_incl_host": round(wall_ms / args.steps, 5), "load_seconds": round(load_s, 1),
         }

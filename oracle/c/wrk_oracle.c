@@ -264,6 +264,12 @@ void orc_v7_decode(const orc_model* m, float* state, uint32_t token, float* logi
     matvec(m->head, tmp, logits, D, m->num_vocab);
 }
 
+void orc_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#endif
+}
+
 int orc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -38,6 +38,28 @@ lib.orc_dequant_f16.argtypes = [C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p]
 lib.orc_v7_decode.restype = None
 lib.orc_v7_decode.argtypes = [C.POINTER(OrcModel), C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
 lib.orc_num_threads.restype = C.c_int
+lib.orc_set_threads.restype = None
+lib.orc_set_threads.argtypes = [C.c_int]
+
+
+def usable_cpus() -> int:
+    """CPUs this process may really use: affinity mask capped by the cgroup CPU quota (a GPU box gives a
+    16-CPU share of a much larger host; OpenMP's default of one thread per host core oversubscribes it)."""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(q / p + 0.5)))
+        except Exception:
+            pass
+    return max(1, min(n, int(os.environ.get("WRK_ORACLE_THREADS", "16"))))
 
 
 class CModel:
@@ -91,6 +113,7 @@ class CModel:
 
 def time_decode(gguf_bytes, first_token: int, seconds: float = 15.0):
     """bench.py cpu_baseline: greedy decode for about `seconds` of CPU time on the host cores."""
+    lib.orc_set_threads(usable_cpus())
     model = CModel(gguf_bytes)
     tok = int(first_token)
     tok = int(model.decode(tok).argmax())          # warm-up (page in the weights)

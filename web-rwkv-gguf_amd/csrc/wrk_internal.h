@@ -157,6 +157,14 @@ struct MatJob {
     DTensor res{};
     float* amax_val = nullptr;      // optional fused arg-max partials [num_wg][ntok]
     uint32_t* amax_idx = nullptr;
+    // fused decode prologue / epilogue (single input vector only; matvec() returns -3 if it cannot honour them)
+    uint32_t pro = 0;               // 1: input = mix(LN(in; ln_w, ln_b, pro_eps), prev, mixw)
+    float pro_eps = 0.0f;
+    const void *ln_w = nullptr, *ln_b = nullptr, *mixw = nullptr;
+    const float* prev = nullptr;    // f32 shift-state row of this sequence
+    void* ln_out = nullptr;         // f16 [K]: LN(in), published by the first workgroup of the job
+    const void* carry_src = nullptr;    // epilogue: carry_dst[row] = carry_src[row]
+    float* carry_dst = nullptr;
 };
 uint32_t matvec_num_wg(const MatJob* jobs, int njobs, int num_cu, uint32_t* rows_per_wg);
 int matvec(hipStream_t s, const MatJob* jobs, int njobs, int num_cu);

@@ -195,6 +195,34 @@ __device__ __forceinline__ void groups_accumulate(const Group& lo, const Group& 
     }
 }
 
+// ------------------------------------------------------------------ launch parameters
+constexpr int MAX_JOBS = 8;
+
+struct JobDev {
+    const uint8_t* w;
+    uint32_t kind, flags, k, m, row_bytes, act;
+    uint32_t rows_per_wg, wg_begin;    // first workgroup (in x) of this job
+    uint32_t has_res;                  // fused residual: out = round_out(act(acc)) + res   (matmul + TensorOp::add)
+    DTensor in, out, res;
+    float* amax_val;                   // optional fused arg-max partials: [num_wg][ntok] (value, row)
+    uint32_t* amax_idx;
+    // optional fused prologue (single-token decode only): the input is x_in = mix(LN(in), prev, mixw)  (layer_norm +
+    // token_shift REVERSED); the first workgroup of the job also stores LN(in) to ln_out for the later state carry
+    uint32_t pro;
+    float pro_eps;
+    const f16 *ln_w, *ln_b, *mixw;
+    const float* prev;
+    f16* ln_out;
+    // optional fused shift-state carry in the epilogue: carry_dst[row] = carry_src[row] (channel_mix_v7's state write)
+    const f16* carry_src;
+    float* carry_dst;
+};
+
+struct MatvecParams {
+    JobDev jobs[MAX_JOBS];
+    int njobs;
+};
+
 // ------------------------------------------------------------------ per-kind chunk load / decode
 // A chunk is 16 bytes of a row's quant plane.  `load_raw` only ISSUES the global loads of chunk c
 // (quants non-temporal: each weight byte is read once per token; side data through the caches),
@@ -374,6 +402,53 @@ __device__ __forceinline__ XRegs load_x(const f16* __restrict__ x, uint32_t c, b
     return r;
 }
 
+// LN statistics of a dense f16 row, computed by ONE wave (every wave of a launch does this redundantly: the row is
+// a few KB and L2 resident, and the two reductions are DPP-only).  Two passes over the row (second pass hits L1).
+__device__ __forceinline__ void wave_ln_stats(const f16* __restrict__ x, uint32_t d, float eps, uint32_t lane, float& mean, float& dev) {
+    const uint32_t nvec = d >> 3;
+    float s = 0.0f;
+    for (uint32_t v = lane; v < nvec; v += 64) s += sum8(*(const f16x8*)(x + v * 8));
+    mean = wave_sum(s) / (float)d;
+    float q = 0.0f;
+    for (uint32_t v = lane; v < nvec; v += 64) {
+        const f16x8 xv = *(const f16x8*)(x + v * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float dl = (float)xv[e] - mean; q += dl * dl; }
+    }
+    dev = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
+}
+
+// x_in[off..off+8) = f16(mix(f16(LN(x)), prev, mixw))
+__device__ __forceinline__ f16x8 ln_mix8(const JobDev& J, const f16* __restrict__ x, uint32_t off, float mean, float dev, f16x8* ln_only) {
+    const f16x8 xv = *(const f16x8*)(x + off), wv = *(const f16x8*)(J.ln_w + off), bv = *(const f16x8*)(J.ln_b + off);
+    f16x8 y, o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) y[e] = (f16)__builtin_fmaf(((float)xv[e] - mean) * dev, (float)wv[e], (float)bv[e]);
+    if (ln_only) { *ln_only = y; return y; }
+    const f16x8 mv = *(const f16x8*)(J.mixw + off);
+    const f32x4 p0 = *(const f32x4*)(J.prev + off), p1 = *(const f32x4*)(J.prev + off + 4);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (f16)wgsl_mix((float)y[e], e < 4 ? p0[e & 3] : p1[e & 3], (float)mv[e]);
+    return o;
+}
+
+template <int KIND>
+__device__ __forceinline__ XRegs load_x_pro(const JobDev& J, const f16* __restrict__ x, uint32_t c, bool valid, float mean, float dev) {
+    XRegs r;
+    const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    r.v[0] = r.v[1] = r.v[2] = r.v[3] = z;
+    r.s[0] = r.s[1] = 0.0f;
+    if (!valid) return r;
+    uint32_t lo, hi;
+    chunk_xoff<KIND>(c, lo, hi);
+    r.v[0] = ln_mix8(J, x, lo, mean, dev, nullptr);
+    if (KIND != WRK_MAT_F16) r.v[1] = ln_mix8(J, x, lo + 8, mean, dev, nullptr);
+    if (KIND != WRK_MAT_F16 && KIND != WRK_MAT_Q8_0) { r.v[2] = ln_mix8(J, x, hi, mean, dev, nullptr); r.v[3] = ln_mix8(J, x, hi + 8, mean, dev, nullptr); }
+    if (KIND != WRK_MAT_F16) r.s[0] = sum8(r.v[0]) + sum8(r.v[1]);
+    if (KIND != WRK_MAT_F16 && KIND != WRK_MAT_Q8_0) r.s[1] = sum8(r.v[2]) + sum8(r.v[3]);
+    return r;
+}
+
 __device__ __forceinline__ float dot16r(const f16x2 (&q)[8], const f16x8 xa, const f16x8 xb) {
     float acc = 0.0f;
     acc = __builtin_amdgcn_fdot2(q[0], __builtin_shufflevector(xa, xa, 0, 1), acc, false);
@@ -415,23 +490,6 @@ __device__ __forceinline__ float dot_raw_reg(const Raw& r, uint32_t c, const XRe
 }
 
 // ------------------------------------------------------------------ the kernel
-constexpr int MAX_JOBS = 8;
-
-struct JobDev {
-    const uint8_t* w;
-    uint32_t kind, flags, k, m, row_bytes, act;
-    uint32_t rows_per_wg, wg_begin;    // first workgroup (in x) of this job
-    uint32_t has_res;                  // fused residual: out = round_out(act(acc)) + res   (matmul + TensorOp::add)
-    DTensor in, out, res;
-    float* amax_val;                   // optional fused arg-max partials: [num_wg][ntok] (value, row)
-    uint32_t* amax_idx;
-};
-
-struct MatvecParams {
-    JobDev jobs[MAX_JOBS];
-    int njobs;
-};
-
 template <int KIND, bool R16, int NB>
 __device__ __forceinline__ void matvec_body(const JobDev& J, unsigned char* smem) {
     const uint32_t K = J.k;
@@ -587,8 +645,17 @@ __device__ __forceinline__ void matvec_body_reg(const JobDev& J, unsigned char* 
     issue(0);       // weights first: they do not depend on the activations
     const f16* xin = (const f16*)J.in.p + dt_index(J.in, 0, 0, 0);
     XRegs x[XI];
+    if (J.pro) {
+        float mean, dev;
+        wave_ln_stats(xin, K, J.pro_eps, lane, mean, dev);
 #pragma unroll
-    for (int ci = 0; ci < XI; ++ci) x[ci] = load_x<KIND>(xin, cbase + 64 * ci, cbase + 64 * ci < nch);
+        for (int ci = 0; ci < XI; ++ci) x[ci] = load_x_pro<KIND>(J, xin, cbase + 64 * ci, cbase + 64 * ci < nch, mean, dev);
+        if (J.ln_out && blockIdx.x == J.wg_begin)       // one workgroup publishes LN(x) for the state carry
+            for (uint32_t v = tid; v < (K >> 3); v += 256) { f16x8 y; ln_mix8(J, xin, v * 8, mean, dev, &y); *(f16x8*)(J.ln_out + v * 8) = y; }
+    } else {
+#pragma unroll
+        for (int ci = 0; ci < XI; ++ci) x[ci] = load_x<KIND>(xin, cbase + 64 * ci, cbase + 64 * ci < nch);
+    }
 
     float* part = (float*)smem;                 // KS == 4: [32 rows][4 waves]
     float best_v = -3.0e38f;
@@ -597,6 +664,7 @@ __device__ __forceinline__ void matvec_body_reg(const JobDev& J, unsigned char* 
         float o = act_apply(J.act, v);
         if (J.has_res) o = dt_round(J.out, o) + dt_load(J.res, dt_index(J.res, r, 0, 0));
         dt_store(J.out, dt_index(J.out, r, 0, 0), o);
+        if (J.carry_dst) J.carry_dst[r] = (float)J.carry_src[r];
         if (o > best_v || (o == best_v && r < best_i)) { best_v = o; best_i = r; }
     };
     for (uint32_t ri0 = 0; ri0 < nrows; ri0 += RB) {
@@ -768,6 +836,8 @@ static int launch_matvec(hipStream_t s, const MatvecParams& P, uint32_t total_wg
         else { if (k != quant) nquant = 2; if (jr != r16) mixed_r16 = true; }
     }
     matvec_fn fn = nullptr;
+    bool needs_reg = false;     // fused prologue / state carry exist only in the register-input decode kernel
+    for (int j = 0; j < P.njobs; ++j) needs_reg = needs_reg || P.jobs[j].pro || P.jobs[j].carry_dst;
     if (NB == 1 && tok_groups == 1 && nquant <= 1 && !mixed_r16) {
         fn = pick_reg(P, nquant ? quant : -1, has_f16, r16);
         if (fn) {
@@ -775,6 +845,7 @@ static int launch_matvec(hipStream_t s, const MatvecParams& P, uint32_t total_wg
             return 0;
         }
     }
+    if (needs_reg) return -3;
     if (nquant >= 2 || mixed_r16) fn = (matvec_fn)matvec_kernel<NB, -1, -1, false>;
     else if (nquant == 0) fn = pick_kernel<NB>(WRK_MAT_F16, WRK_MAT_F16, false);
     else fn = pick_kernel<NB>(quant, has_f16 ? WRK_MAT_F16 : quant, r16);
@@ -819,6 +890,9 @@ int matvec(hipStream_t s, const MatJob* jobs, int njobs, int num_cu) {
         d.row_bytes = jobs[j].row_bytes; d.act = jobs[j].act; d.rows_per_wg = rpw; d.wg_begin = wg;
         d.in = jobs[j].in; d.out = jobs[j].out; d.res = jobs[j].res; d.has_res = jobs[j].has_res;
         d.amax_val = jobs[j].amax_val; d.amax_idx = jobs[j].amax_idx;
+        d.pro = jobs[j].pro; d.pro_eps = jobs[j].pro_eps; d.ln_w = (const f16*)jobs[j].ln_w; d.ln_b = (const f16*)jobs[j].ln_b;
+        d.mixw = (const f16*)jobs[j].mixw; d.prev = jobs[j].prev; d.ln_out = (f16*)jobs[j].ln_out;
+        d.carry_src = (const f16*)jobs[j].carry_src; d.carry_dst = jobs[j].carry_dst;
         wg += (jobs[j].m + rpw - 1) / rpw;
     }
     const uint32_t kpad = (kmax + 15u) & ~15u;

@@ -379,7 +379,7 @@ int32_t wrk_v7_infer(wrk_ctx* ctx, wrk_v7_model* m, wrk_v7_state* st, const uint
         rc = wrk_buf_write_raw(ctx, m->s.input, emb_rows, (size_t)T * D * 2);
         if (rc != WRK_OK) return rc;
     }
-    if (fused) rc = m->enqueue_fused_decode(st, T, NH, identity, tokens != nullptr, NH && argmax, false);
+    if (fused) rc = m->enqueue_fused_decode(st, T, NH, identity, tokens != nullptr, NH && argmax, false, cursors[0] & 0xff);
     else {
         rc = m->enqueue_ops(st, T, NH, identity);
         if (rc == WRK_OK && NH && argmax) wrk::argmax_rows(ctx->stream, m->s.head_o, V, V, NH, m->s.argmax);
@@ -422,7 +422,7 @@ int32_t wrk_v7_generate_greedy(wrk_ctx* ctx, wrk_v7_model* m, wrk_v7_state* st, 
     const char* ng = getenv("WRK_NO_GRAPH");
     const bool eager = ng && ng[0] == '1';
     auto enqueue_step = [&]() -> int32_t {
-        if (mode == 1) return m->enqueue_fused_decode(st, B, B, true, true, true, true);
+        if (mode == 1) return m->enqueue_fused_decode(st, B, B, true, true, true, true, 0);
         wrk::gather_rows_f16(ctx->stream, m->emb->ptr, m->s.tokens, m->s.input, D, B);
         int32_t r = m->enqueue_ops(st, B, B, true);
         if (r != WRK_OK) return r;

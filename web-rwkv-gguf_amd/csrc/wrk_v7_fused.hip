@@ -154,6 +154,7 @@ struct HeadParams {
     f16* out;                                   // att_x [T][D]
     float* state;                               // layer state base: element (batch, row, c) at state[(batch*(S+2)+row)*D + c]
     const uint32_t* cursors;
+    const f16* shift_src;                       // optional [T][D]: copied into state row 0 (att shift carry of a fused K0)
     float gn_eps, l2_eps;
 };
 
@@ -232,6 +233,7 @@ __global__ void __launch_bounds__(256) head_kernel(const HeadParams P) {
         }
     }
     const float gnw = (float)P.gn_w[c0 + i], gnb = (float)P.gn_b[c0 + i], rkw = (float)P.r_k[c0 + i];
+    if (P.shift_src && g4 == 1) P.state[(size_t)batch * (S + 2) * D + c0 + i] = (float)P.shift_src[(size_t)t * D + c0 + i];
     __syncthreads();
     // kk <- l2_norm(kk) over the head; a~ = -kk, b~ = kk * a
     if (g4 == 0) {
@@ -340,7 +342,7 @@ static wrk::MatJob job(const wrk_matrix* m, DTensor in, DTensor out, uint32_t ac
 }
 
 int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_t NH, bool identity_headers, bool from_tokens,
-                                            bool want_argmax, bool advance) {
+                                            bool want_argmax, bool advance, uint32_t cursor0_batch) {
     using namespace wrk;
     hipStream_t q = ctx->stream;
     const uint32_t D = d.num_emb, F = d.num_hidden, H = d.num_head, S = D / H, V = d.num_vocab;
@@ -380,7 +382,21 @@ int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_
     for (uint32_t li = 0; li < d.num_layer; ++li) {
         const wrk_v7_layer_desc& L = layers[li];
         float* lst = st->layer_ptr(li);
-        {   // K0
+        // batch-1 decode can fold LN + token shift into the matvec's input load (5 launches per layer instead of 7).
+        // Measured on MI355X (round 1): SLOWER than the separate LN kernel (1.14 vs 0.905 ms/token) because every wave
+        // pays three dependent L2 round trips before its first dot product; kept behind WRK_FUSE_LN=1 for experiments.
+        static const bool fuse_ln = [] { const char* e = getenv("WRK_FUSE_LN"); return e && e[0] == '1'; }();
+        bool single = fuse_ln && (T == 1);
+        if (single) {       // the fused prologue exists only in the single-kind (+F16) register kernels
+            uint32_t kinds = 0;
+            const wrk_matrix* ms[] = {L.w_r, L.w_k, L.w_v};
+            for (const wrk_matrix* m : ms) if (m->kind != WRK_MAT_F16) kinds |= 1u << (m->kind & 31);
+            if (__builtin_popcount(kinds) > 1 || L.w_r->flags != L.w_k->flags || L.w_r->flags != L.w_v->flags || D > 2048 * 4) single = false;
+        }
+        uint32_t batch0 = 0;
+        if (single) batch0 = cursor0_batch;
+        float* row0 = lst + (size_t)batch0 * (S + 2) * D;                    // att shift state of the sequence
+        if (!single) {   // K0
             LnMixParams P{};
             P.src = (const f16*)s.x; P.ln_w = (const f16*)L.ln1_w->ptr; P.ln_b = (const f16*)L.ln1_b->ptr; P.eps = 1.0e-5f;
             P.d = D; P.nmix = 6;
@@ -397,7 +413,17 @@ int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_
                               job(L.a1, vec(s.ax), vec(s.aux_a, d.lora_a), WRK_ACT_NONE),
                               job(L.g1, vec(s.gx), vec(s.aux_g, d.lora_g), WRK_ACT_SIGMOID),
                               job(li ? L.v1 : L.a1, vec(s.vx), vec(s.aux_v, d.lora_v), WRK_ACT_NONE)};
-            if (matvec(q, jobs, li ? 7 : 6, ctx->num_cu) != 0) return wrk_fail(ctx, WRK_E_ARG, "fused K1 rejected");
+            if (single) {
+                const wrk_buf* mx[7] = {L.x_r, L.x_k, L.x_v, L.x_w, L.x_a, L.x_g, L.x_v};
+                for (int i = 0; i < 7; ++i) {
+                    jobs[i].in = vec(s.x);
+                    jobs[i].pro = 1; jobs[i].pro_eps = 1.0e-5f; jobs[i].ln_w = L.ln1_w->ptr; jobs[i].ln_b = L.ln1_b->ptr;
+                    jobs[i].mixw = mx[i]->ptr; jobs[i].prev = row0;
+                }
+                jobs[0].ln_out = s.ln_tmp;      // LN(x): becomes the att shift state in K2
+            }
+            const int rc = matvec(q, jobs, li ? 7 : 6, ctx->num_cu);
+            if (rc != 0) return wrk_fail(ctx, WRK_E_ARG, "fused K1 rejected (%d)", rc);
         }
         {   // K2
             HeadParams P{};
@@ -413,6 +439,7 @@ int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_
             P.r = (const f16*)s.r; P.k = (const f16*)s.k; P.v = (const f16*)s.v;
             P.v_first = (f16*)s.att_v0; P.out = (f16*)s.att_x;
             P.state = lst; P.cursors = s.cursors; P.gn_eps = 64.0e-5f; P.l2_eps = 1.0e-12f;
+            P.shift_src = single ? (const f16*)s.ln_tmp : nullptr;     // fused K0: the state carry happens here
             head_kernel<<<dim3(H, T), 256, 0, q>>>(P);
         }
         {   // K3: x += W_o . att_x
@@ -420,7 +447,8 @@ int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_
             j.has_res = 1; j.res = vec(s.x);
             if (matvec(q, &j, 1, ctx->num_cu) != 0) return wrk_fail(ctx, WRK_E_ARG, "fused K3 rejected");
         }
-        {   // K4
+        float* rowf = lst + ((size_t)batch0 * (S + 2) + (S + 1)) * D;          // ffn shift state of the sequence
+        if (!single) {   // K4
             LnMixParams P{};
             P.src = (const f16*)s.x; P.ln_w = (const f16*)L.ln2_w->ptr; P.ln_b = (const f16*)L.ln2_b->ptr; P.eps = 1.0e-5f;
             P.d = D; P.nmix = 1; P.mix[0] = (const f16*)L.ffn_x_k->ptr; P.out[0] = (f16*)s.ffn_kx;
@@ -429,11 +457,17 @@ int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_
         }
         {   // K5
             MatJob j = job(L.ffn_w_k, vec(s.ffn_kx), vec(s.ffn_k, F), WRK_ACT_SQUARED_RELU);
+            if (single) {
+                j.in = vec(s.x);
+                j.pro = 1; j.pro_eps = 1.0e-5f; j.ln_w = L.ln2_w->ptr; j.ln_b = L.ln2_b->ptr; j.mixw = L.ffn_x_k->ptr; j.prev = rowf;
+                j.ln_out = s.ffn_x;             // LN(x): becomes the ffn shift state in K6's epilogue
+            }
             if (matvec(q, &j, 1, ctx->num_cu) != 0) return wrk_fail(ctx, WRK_E_ARG, "fused K5 rejected");
         }
         {   // K6: x += W_v . relu(k)^2
             MatJob j = job(L.ffn_w_v, vec(s.ffn_k, F), vec(s.x), WRK_ACT_NONE);
             j.has_res = 1; j.res = vec(s.x);
+            if (single) { j.carry_src = s.ffn_x; j.carry_dst = rowf; }
             if (matvec(q, &j, 1, ctx->num_cu) != 0) return wrk_fail(ctx, WRK_E_ARG, "fused K6 rejected");
         }
         if ((li + 1) % d.rescale == 0) wrk::affine(q, vec(s.x), 0.5f, 0.0f);
