@@ -92,3 +92,36 @@ def test_matrix_create_rejects_bad_input(ctx):
     mat = wrk.Matrix(ctx, "Q8_0", 64, 4, make("Q8_0", 64, 4, 1))
     with pytest.raises(wrk.WrkError):
         mat.matmul_op(ctx.zeros([32, 1, 1]), ctx.zeros([4, 1, 1]))            # K mismatch
+
+
+# ------------------------------------------------------------------ MFMA dequant-GEMM (turbo path, >= 16 tokens)
+GEMM_CASES = [("Q4_K", 2048, 100), ("Q4_K", 512, 64), ("Q5_K", 1024, 48), ("Q6_K", 512, 130), ("Q6_K", 2048, 33),
+              ("Q8_0", 96 * 2, 40), ("Q8_0", 1024, 64), ("F16", 96, 256), ("F16", 2048, 70), ("F32", 256, 64)]
+
+
+@pytest.mark.parametrize("kind,k,m", GEMM_CASES)
+@pytest.mark.parametrize("T,B", [(16, 1), (32, 1), (37, 1), (128, 1), (8, 3)])
+def test_gemm_matches_oracle(ctx, kind, k, m, T, B):
+    """Matrix::matmul_op(turbo=true) (matrix.rs:185-196) on the matrix cores: exact-weight f32 contraction."""
+    raw = make(kind, k, m, k * 3 + m)
+    mat = wrk.Matrix(ctx, kind, k, m, raw)
+    w = dq.dequantize(kind, raw, k * m, round_f16=(kind == "F32")).reshape(m, k)
+    x = np.random.default_rng(T + B).standard_normal((B, T, k)).astype(np.float16)
+    out = ctx.zeros([m, T, B], np.float32)
+    mat.matmul_op(ctx.tensor(x), out, turbo=True)
+    got = out.back().reshape(B, T, m)
+    want = x.astype(np.float64) @ w.astype(np.float64).T
+    bound = 4e-6 * (np.abs(x).astype(np.float64) @ np.abs(w).astype(np.float64).T) + 1e-6
+    assert np.all(np.abs(got - want) <= bound), np.abs(got - want).max()
+
+
+def test_gemm_activation_residual_f16_out_and_vec_agreement(ctx):
+    k, m, T = 512, 72, 48
+    raw = make("Q4_K", k, m, 5)
+    mat = wrk.Matrix(ctx, "Q4_K", k, m, raw)
+    x = np.random.default_rng(2).standard_normal((T, k)).astype(np.float16)
+    a, b = ctx.zeros([m, T, 1]), ctx.zeros([m, T, 1])
+    mat.matmul_op(ctx.tensor(x, [k, T, 1]), a, "squared_relu", turbo=True)
+    mat.matmul_op(ctx.tensor(x, [k, T, 1]), b, "squared_relu", turbo=False)
+    ga, gb = a.back().astype(np.float32), b.back().astype(np.float32)
+    assert np.all(np.abs(ga - gb) <= np.maximum(np.abs(gb), 2.0 ** -14) * 2.0 ** -10 + 1e-6)     # <= 1 f16 ulp apart

@@ -38,6 +38,7 @@ int32_t wrk_ctx_destroy(wrk_ctx* ctx) {
     hipStreamSynchronize(ctx->stream);
     hipStreamSynchronize(ctx->read_stream);
     if (ctx->staging) hipHostFree(ctx->staging);
+    if (ctx->xsum) hipFree(ctx->xsum);
     hipEventDestroy(ctx->read_event);
     hipStreamDestroy(ctx->read_stream);
     hipStreamDestroy(ctx->stream);
@@ -307,7 +308,18 @@ int32_t wrk_op_matmul(wrk_ctx* ctx, const wrk_matrix* mat, const wrk_tensor* inp
     wrk::MatJob j{mat->data, mat->aux, mat->kind, mat->flags, mat->k, mat->m, (uint32_t)mat->row_bytes,
                   make_dtensor(input), make_dtensor(output), act, (uint32_t)sparse};
     int rc = -2;
-    if (turbo) rc = wrk::matmul_mfma(ctx->stream, j, ctx->num_cu);
+    const size_t ntok = (size_t)input->view.shape[1] * input->view.shape[2];
+    if (turbo && ntok >= 16) {
+        const size_t need = ntok * (mat->k / 32 + 1);
+        if (need > ctx->xsum_cap && !ctx->capturing) {      // grow the GEMM scratch (never while capturing)
+            WRK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->xsum) hipFree(ctx->xsum);
+            ctx->xsum = nullptr; ctx->xsum_cap = 0;
+            WRK_HIP(ctx, hipMalloc((void**)&ctx->xsum, need * 4));
+            ctx->xsum_cap = need;
+        }
+        rc = wrk::matmul_mfma(ctx->stream, j, ctx->num_cu, ctx->xsum, ctx->xsum_cap);
+    }
     if (rc == -2) rc = wrk::matvec(ctx->stream, &j, 1, ctx->num_cu);
     WRK_ARG(ctx, rc == 0, "matmul: launch configuration rejected");
     WRK_LAUNCH_CHECK(ctx);

@@ -24,6 +24,8 @@ struct wrk_ctx {
     int num_cu = 256;
     void* staging = nullptr;            // pinned host staging for wrk_buf_write
     size_t staging_bytes = 0;
+    float* xsum = nullptr;              // GEMM scratch: per-32 input sums [tokens][K/32]
+    size_t xsum_cap = 0;
 };
 
 struct wrk_buf {
@@ -168,7 +170,9 @@ struct MatJob {
 };
 uint32_t matvec_num_wg(const MatJob* jobs, int njobs, int num_cu, uint32_t* rows_per_wg);
 int matvec(hipStream_t s, const MatJob* jobs, int njobs, int num_cu);
-int matmul_mfma(hipStream_t s, const MatJob& job, int num_cu);
+// MFMA dequant-GEMM (wrk_gemm.hip); -2 = not applicable (caller uses the matvec kernels).  xsum_scratch: device
+// f32 buffer of at least tokens * K/32 elements (only the K4 kinds use it)
+int matmul_mfma(hipStream_t s, const MatJob& job, int num_cu, float* xsum_scratch, size_t xsum_cap);
 size_t repack_row_bytes(uint32_t kind, uint32_t k);
 int repack_rows(uint32_t kind, uint32_t k, uint32_t m, const uint8_t* src, uint8_t* dst);   // host side
 size_t stored_bytes(uint32_t kind, uint32_t k, uint32_t m);

@@ -910,6 +910,4 @@ int matvec(hipStream_t s, const MatJob* jobs, int njobs, int num_cu) {
     }
 }
 
-int matmul_mfma(hipStream_t, const MatJob&, int) { return -2; }   // provided by wrk_gemm.hip when built
-
 }  // namespace wrk
