@@ -18,7 +18,7 @@ import wrk  # noqa: E402
 BLOCK = {"Q4_K": (256, 144), "Q5_K": (256, 176), "Q6_K": (256, 210), "Q8_0": (32, 34), "F16": (1, 2)}
 
 
-def run(ctx, kind, k, m, nin=1, reps=200, copies=4):
+def run(ctx, kind, k, m, nin=1, reps=200, copies=4, turbo=False):
     be, bb = BLOCK[kind]
     rng = np.random.default_rng(0)
     mats = []
@@ -36,11 +36,11 @@ def run(ctx, kind, k, m, nin=1, reps=200, copies=4):
     x = ctx.tensor(rng.standard_normal((nin, k)).astype(np.float16), [k, nin, 1])
     out = ctx.zeros([m, nin, 1])
     for mt in mats:
-        mt.matmul_op(x, out)
+        mt.matmul_op(x, out, turbo=turbo)
     ctx.sync()
     ctx.check(wrk.hip.wrk_capture_begin(ctx.h))
     for i in range(reps):
-        mats[i % copies].matmul_op(x, out)
+        mats[i % copies].matmul_op(x, out, turbo=turbo)
     prog = C.c_void_p()
     ctx.check(wrk.hip.wrk_capture_end(ctx.h, C.byref(prog)))
     best = 1e9
@@ -52,7 +52,8 @@ def run(ctx, kind, k, m, nin=1, reps=200, copies=4):
         best = min(best, (time.perf_counter() - t0) / reps)
     wrk.hip.wrk_program_destroy(prog)
     gb = mats[0].stream_bytes / 1e9
-    print(f"{kind:5s} K={k:5d} M={m:6d} T={nin}: {best * 1e6:8.2f} us/launch  {gb / best:8.1f} GB/s  ({gb * 1e3:.2f} MB)", flush=True)
+    tf = 2.0 * k * m * nin / best / 1e12
+    print(f"{kind:5s} K={k:5d} M={m:6d} T={nin:4d}{' mfma' if turbo else '     '}: {best * 1e6:8.2f} us/launch  {gb / best:8.1f} GB/s  ({gb * 1e3:.2f} MB)  {tf:7.2f} TFLOP/s", flush=True)
     return best
 
 
@@ -66,4 +67,10 @@ if __name__ == "__main__":
         run(ctx, kind, k, m)
     run(ctx, "Q4_K", 2048, 8192, nin=4)
     run(ctx, "Q4_K", 2048, 8192, nin=8)
+    for n in (16, 32, 64, 128, 512):
+        run(ctx, "Q4_K", 2048, 8192, nin=n, reps=50, turbo=True)
+    for n in (16, 128):
+        run(ctx, "Q4_K", 8192, 2048, nin=n, reps=50, turbo=True)
+        run(ctx, "Q6_K", 2048, 8192, nin=n, reps=50, turbo=True)
+        run(ctx, "F16", 2048, 2048, nin=n, reps=50, turbo=True)
     ctx.close()

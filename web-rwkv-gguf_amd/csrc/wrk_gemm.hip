@@ -20,7 +20,8 @@
 // Integer codes become f16 without arithmetic (code in the low mantissa bits = subnormal code*2^-24, see
 // wrk_matvec.hip); one v_pk_mul_f16 per pair both applies the integer sub-scale and moves them to normal range.
 //
-// Work split: a wave owns 16 rows x (16*NT) tokens; 4 waves (64 rows) per workgroup; grid = (M/64, N/(16*NT)).
+// Work split: a workgroup owns 16 rows x (16*NT) tokens; its 4 waves split K (every 4th block / step) and their
+// partial tiles meet in LDS; grid = (M/16, N/(16*NT)).
 // Lane l: A row = l & 15, k-group g = l >> 4 (8 consecutive k); C column (token) = l & 15, rows 4g..4g+3.
 #include "wrk_device.h"
 
@@ -92,10 +93,11 @@ __global__ void __launch_bounds__(256) xsum32_kernel(DTensor in, float* __restri
 template <int KIND, int NT>
 __global__ void __launch_bounds__(256) gemm_kernel(const GemmParams P) {
     __shared__ float sh_scale[4][16][12];       // per wave: [row][d, mn0..mn7] staged by the row lanes (K4 kinds)
+    __shared__ float sh_tot[3][NT][4][64];      // K-split partial sums of waves 1..3
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t r = lane & 15, g = lane >> 4;
-    const uint32_t m0 = blockIdx.x * 64 + wave * 16;
-    if (m0 >= P.m) return;                                          // whole wave out of range (no barriers below)
+    // a workgroup owns 16 rows; its 4 waves split K (wave w takes every 4th block / step) and meet in LDS
+    const uint32_t m0 = blockIdx.x * 16;
     const uint32_t row = min(m0 + r, P.m - 1);
     const uint8_t* wrow = P.w + (size_t)row * P.row_bytes;
     const uint32_t n0 = blockIdx.y * 16 * NT;
@@ -121,7 +123,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmParams P) {
 
     if (KIND == WRK_MAT_F16) {
         const f16* wr = (const f16*)wrow;
-        for (uint32_t k0 = 0; k0 < K; k0 += 32) {
+        for (uint32_t k0 = 32 * wave; k0 < K; k0 += 128) {
             const f16x8 a = (k0 + 8 * g + 8 <= K) ? *(const f16x8*)(wr + k0 + 8 * g) : zero8;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
@@ -131,7 +133,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmParams P) {
         }
     } else if (KIND == WRK_MAT_Q8_0) {
         const uint32_t nblk = K >> 5;
-        for (uint32_t s = 0; s < nblk; ++s) {
+        for (uint32_t s = wave; s < nblk; s += 4) {
             const u32x2 q = *(const u32x2*)(wrow + (size_t)s * 32 + 8 * g);
             // int8 -> (u - 128): subnormal u*2^-24, scaled by 2^15 to u*2^-9 (normal), minus 128*2^-9
             const f16x8 a = add8(mul8(codes8(q.x ^ 0x80808080u, q.y ^ 0x80808080u), 32768.0f), -0.25f);
@@ -150,7 +152,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmParams P) {
             }
         }
     } else if (KIND == WRK_MAT_Q6_K) {
-        for (uint32_t b = 0; b < nb; ++b) {
+        for (uint32_t b = wave; b < nb; b += 4) {
             f32x4v acc[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
@@ -193,7 +195,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmParams P) {
         const uint32_t hoff = KIND == WRK_MAT_Q4_K ? nb * 128 : nb * 160;     // (d, dmin) plane
         const uint32_t soff = hoff + nb * 4;                                   // unpacked scales plane
         const uint32_t k32 = K >> 5;
-        for (uint32_t b = 0; b < nb; ++b) {
+        for (uint32_t b = wave; b < nb; b += 4) {
             // the 16 row lanes of the wave (g == 0) stage d and dmin*m_s of their row for the C-row owners
             const uint32_t dd16 = *(const uint32_t*)(wrow + hoff + (size_t)b * 4);
             const u32x4 sm = *(const u32x4*)(wrow + soff + (size_t)b * 16);
@@ -261,6 +263,20 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmParams P) {
         }
     }
 
+    // combine the four K slices
+    if (wave > 0) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sh_tot[wave - 1][t][i][lane] = total[t][i];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) total[t][i] += (sh_tot[0][t][i][lane] + sh_tot[1][t][i][lane]) + sh_tot[2][t][i][lane];
+
     // store: lane owns rows m0 + 4g + (0..3) of token column r of each tile
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -281,7 +297,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmParams P) {
 
 template <int KIND>
 static void launch_gemm(hipStream_t s, const GemmParams& P) {
-    const uint32_t gx = (P.m + 63) / 64;
+    const uint32_t gx = (P.m + 15) / 16;
     // tokens per wave: enough tiles to amortise the decode, few enough to keep >= ~2 waves per SIMD
     if (P.n > 64) gemm_kernel<KIND, 4><<<dim3(gx, (P.n + 63) / 64), 256, 0, s>>>(P);
     else if (P.n > 16) gemm_kernel<KIND, 2><<<dim3(gx, (P.n + 31) / 32), 256, 0, s>>>(P);

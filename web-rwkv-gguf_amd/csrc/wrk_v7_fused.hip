@@ -365,6 +365,18 @@ int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_
         return WRK_OK;
     }
     auto vec = [&](void* p, uint32_t c = 0) { return make_dense(p, WRK_F16, c ? c : D, T); };
+    // batched decode (many sequences): each matrix goes to the MFMA GEMM; few sequences: one multi-matrix matvec launch
+    auto run_jobs = [&](MatJob* jobs, int n) -> int {
+        if (T >= 9) {
+            for (int i = 0; i < n; ++i) {
+                int rc = matmul_mfma(q, jobs[i], ctx->num_cu, ctx->xsum, ctx->xsum_cap);
+                if (rc == -2) rc = matvec(q, &jobs[i], 1, ctx->num_cu);
+                if (rc != 0) return rc;
+            }
+            return 0;
+        }
+        return matvec(q, jobs, n, ctx->num_cu);
+    };
 #define LN(P, n)                                                                             \
     do {                                                                                     \
         if (ln_mix(q, P, n) != 0) return wrk_fail(ctx, WRK_E_UNSUPPORTED, "ln_mix shape");   \
@@ -422,7 +434,7 @@ int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_
                 }
                 jobs[0].ln_out = s.ln_tmp;      // LN(x): becomes the att shift state in K2
             }
-            const int rc = matvec(q, jobs, li ? 7 : 6, ctx->num_cu);
+            const int rc = run_jobs(jobs, li ? 7 : 6);
             if (rc != 0) return wrk_fail(ctx, WRK_E_ARG, "fused K1 rejected (%d)", rc);
         }
         {   // K2
@@ -445,7 +457,7 @@ int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_
         {   // K3: x += W_o . att_x
             MatJob j = job(L.w_o, vec(s.att_x), vec(s.x), WRK_ACT_NONE);
             j.has_res = 1; j.res = vec(s.x);
-            if (matvec(q, &j, 1, ctx->num_cu) != 0) return wrk_fail(ctx, WRK_E_ARG, "fused K3 rejected");
+            if (run_jobs(&j, 1) != 0) return wrk_fail(ctx, WRK_E_ARG, "fused K3 rejected");
         }
         float* rowf = lst + ((size_t)batch0 * (S + 2) + (S + 1)) * D;          // ffn shift state of the sequence
         if (!single) {   // K4
@@ -462,13 +474,13 @@ int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_
                 j.pro = 1; j.pro_eps = 1.0e-5f; j.ln_w = L.ln2_w->ptr; j.ln_b = L.ln2_b->ptr; j.mixw = L.ffn_x_k->ptr; j.prev = rowf;
                 j.ln_out = s.ffn_x;             // LN(x): becomes the ffn shift state in K6's epilogue
             }
-            if (matvec(q, &j, 1, ctx->num_cu) != 0) return wrk_fail(ctx, WRK_E_ARG, "fused K5 rejected");
+            if (run_jobs(&j, 1) != 0) return wrk_fail(ctx, WRK_E_ARG, "fused K5 rejected");
         }
         {   // K6: x += W_v . relu(k)^2
             MatJob j = job(L.ffn_w_v, vec(s.ffn_k, F), vec(s.x), WRK_ACT_NONE);
             j.has_res = 1; j.res = vec(s.x);
             if (single) { j.carry_src = s.ffn_x; j.carry_dst = rowf; }
-            if (matvec(q, &j, 1, ctx->num_cu) != 0) return wrk_fail(ctx, WRK_E_ARG, "fused K6 rejected");
+            if (run_jobs(&j, 1) != 0) return wrk_fail(ctx, WRK_E_ARG, "fused K6 rejected");
         }
         if ((li + 1) % d.rescale == 0) wrk::affine(q, vec(s.x), 0.5f, 0.0f);
     }
