@@ -161,10 +161,17 @@ int32_t wrk_op_layer_norm(wrk_ctx* ctx, const wrk_buf* w, const wrk_buf* b, cons
 int32_t wrk_op_group_norm(wrk_ctx* ctx, const wrk_buf* w, const wrk_buf* b, const wrk_tensor* x, float eps);
 /* TensorOp::l2_norm (ops.rs:642-691): x[S, H, T] */
 int32_t wrk_op_l2_norm(wrk_ctx* ctx, const wrk_tensor* x, float eps);
-/* TensorOp::token_shift (ops.rs:2119-2187): cursors u32 [T]; time_mix f16 [C]; state f32 view
- * [C, 1, B]; input/output [C, T, 1] */
-int32_t wrk_op_token_shift(wrk_ctx* ctx, const wrk_buf* cursors, const wrk_buf* time_mix, const wrk_tensor* state,
+/* TensorOp::token_shift (ops.rs:2119-2187): cursors u32 [T]; time_mix [C, 1 or T, I] (one factor vector, or V6's
+ * per-token factors, I shifts per call); state f32 view [C, 1, B]; input [C, T, 1]; output [C, T, I] */
+int32_t wrk_op_token_shift(wrk_ctx* ctx, const wrk_buf* cursors, const wrk_tensor* time_mix, const wrk_tensor* state,
                            const wrk_tensor* input, const wrk_tensor* output, int32_t reversed);
+/* TensorOp::transpose (ops.rs:2847-2905): output[C, B, T] = input[C, T, B] */
+int32_t wrk_op_transpose(wrk_ctx* ctx, const wrk_tensor* input, const wrk_tensor* output);
+/* TensorOp::time_mix_v6 (ops.rs:2327-2394): time_decay/k/v/r/x [S, H, T]; time_first f32 [S*H]; state f32 view [C, S+1, B] */
+int32_t wrk_op_time_mix_v6(wrk_ctx* ctx, const wrk_buf* cursors, const wrk_tensor* time_decay, const wrk_buf* time_first,
+                           const wrk_tensor* state, const wrk_tensor* k, const wrk_tensor* v, const wrk_tensor* r, const wrk_tensor* x);
+/* TensorOp::channel_mix (ops.rs:2586-2641, V6): x <- sigmoid(r) * v, plus the ffn shift-state save */
+int32_t wrk_op_channel_mix(wrk_ctx* ctx, const wrk_buf* cursors, const wrk_tensor* state, const wrk_tensor* r, const wrk_tensor* v, const wrk_tensor* x);
 /* TensorOp::add_activate / mul_activate (ops.rs:1953-2117): output = act_o(act_x(input) (+|*) act_y(output)),
  * input broadcast over T/B when its extent is 1 */
 int32_t wrk_op_add(wrk_ctx* ctx, const wrk_tensor* input, const wrk_tensor* output, uint32_t act_x, uint32_t act_y, uint32_t act_o);
@@ -251,6 +258,47 @@ int32_t wrk_v7_infer(wrk_ctx* ctx, wrk_v7_model* model, wrk_v7_state* state,
  * step shape is built on first use and replayed.  elapsed_ms_or_null receives the HIP-event time
  * of the `steps` replays on the context's stream. */
 int32_t wrk_v7_generate_greedy(wrk_ctx* ctx, wrk_v7_model* model, wrk_v7_state* state,
+                               const uint32_t* first_tokens, uint32_t num_batch, uint32_t steps,
+                               uint32_t* out_tokens, float* last_logits_or_null, float* elapsed_ms_or_null, uint32_t mode);
+
+/* ---------------------------------------------------------------- RWKV-6 (v6::Model, src/runtime/v6.rs)
+ * Same chunk semantics, state layout ([D, S+2, B] per layer: v6.rs:150-214 == v7) and entry points as the V7
+ * runner; one kernel per reference TensorOp (v6.rs:701-958), decode steps replayed from a hipGraph. */
+typedef struct wrk_v6_model wrk_v6_model;
+
+typedef struct wrk_v6_layer_desc {
+    const wrk_buf *ln1_w, *ln1_b, *ln2_w, *ln2_b;               /* f16 [D] */
+    const wrk_buf *time_decay;                                  /* f16 [D]                        (v6.rs:1051) */
+    const wrk_buf *time_first;                                  /* f32 [D] = [S, H]               (v6.rs:1052, load_vector_f32) */
+    const wrk_buf *time_mix_x;                                  /* f16 [D] */
+    const wrk_buf *time_mix;                                    /* f16 [D, 1, 5] = w, k, v, r, g  (v6.rs:1054-1071) */
+    const wrk_matrix *time_decay_w1, *time_decay_w2, *time_mix_w1;
+    const wrk_matrix *time_mix_w2[5];                           /* the batched [R, D, 5] matrix as five [R -> D] matrices */
+    const wrk_matrix *w_k, *w_v, *w_r, *w_g, *w_o;
+    const wrk_buf *gn_w, *gn_b;
+    const wrk_buf *ffn_mix_k, *ffn_mix_r;
+    const wrk_matrix *ffn_w_k, *ffn_w_v, *ffn_w_r;
+} wrk_v6_layer_desc;
+
+typedef struct wrk_v6_model_desc {
+    uint32_t num_layer, num_emb, num_hidden, num_vocab, num_head;
+    uint32_t time_mix, time_decay;                              /* v6::CustomInfo (v6.rs:53-59) */
+    uint32_t rescale;                                           /* default 6 (v6.rs:49) */
+    const wrk_buf *ln0_w, *ln0_b, *ln_out_w, *ln_out_b, *emb_f16;
+    const wrk_matrix* head;
+    const wrk_v6_layer_desc* layers;
+} wrk_v6_model_desc;
+
+int32_t wrk_v6_model_create(wrk_ctx* ctx, const wrk_v6_model_desc* desc, wrk_v6_model** out);
+int32_t wrk_v6_model_destroy(wrk_v6_model* model);
+size_t wrk_v6_model_token_bytes(const wrk_v6_model* model, uint32_t num_batch);
+/* v6::Bundle::new state allocation; the handle type is shared with V7 (identical layout) */
+int32_t wrk_v6_state_create(wrk_ctx* ctx, const wrk_v6_model* model, uint32_t num_batch, wrk_v7_state** out);
+/* as wrk_v7_infer / wrk_v7_generate_greedy (mode is ignored: op-by-op kernels) */
+int32_t wrk_v6_infer(wrk_ctx* ctx, wrk_v6_model* model, wrk_v7_state* state,
+                     const uint32_t* tokens, const uint16_t* emb_rows, const uint32_t* cursors, uint32_t num_token,
+                     const uint32_t* headers, uint32_t num_header, float* logits, uint32_t* argmax, uint32_t mode);
+int32_t wrk_v6_generate_greedy(wrk_ctx* ctx, wrk_v6_model* model, wrk_v7_state* state,
                                const uint32_t* first_tokens, uint32_t num_batch, uint32_t steps,
                                uint32_t* out_tokens, float* last_logits_or_null, float* elapsed_ms_or_null, uint32_t mode);
 

@@ -50,9 +50,9 @@ int32_t wrk_gguf_raw(const wrk_gguf* g, const char* name, uint32_t* ggml_type, c
 int32_t wrk_gguf_meta_u64(const wrk_gguf* g, const char* key, uint64_t* out);
 
 typedef struct wrk_model_info {         /* ModelInfo (model.rs:30-63) + v7::CustomInfo */
-    uint32_t version;                   /* 7 */
+    uint32_t version;                   /* 6 or 7 */
     uint32_t num_layer, num_emb, num_hidden, num_vocab, num_head;
-    uint32_t lora_w, lora_a, lora_g, lora_v;
+    uint32_t lora_w, lora_a, lora_g, lora_v;   /* V7: w/a/g/v ranks; V6: lora_w = time_mix, lora_a = time_decay (v6::CustomInfo) */
 } wrk_model_info;
 /* Loader::info */
 int32_t wrk_gguf_info(const wrk_gguf* g, wrk_model_info* out);
@@ -98,6 +98,8 @@ int32_t wrk_runtime_destroy(wrk_runtime* rt);
 int32_t wrk_runtime_info(const wrk_runtime* rt, wrk_model_info* out);
 wrk_v7_model* wrk_runtime_model(wrk_runtime* rt);
 wrk_v7_state* wrk_runtime_state(wrk_runtime* rt);
+/* non-NULL when the file is an RWKV-6 model (ModelVersion::V6); wrk_runtime_model is NULL then */
+wrk_v6_model* wrk_runtime_model_v6(wrk_runtime* rt);
 
 /* runtime.infer(input) -> (input, output) (mod.rs:238-263): dispatch the next chunk, load, submit,
  * read back, then input.step().  `logits` receives the rows of every batch back to back

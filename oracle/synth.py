@@ -160,3 +160,83 @@ def make_v7_gguf(cfg: V7Config, seed: int = 42, mat: str = "Q4_K", head: str = "
         ("rwkv7.attention.layer_norm_epsilon", "f32", 1e-5),
     ]
     return write_gguf(meta, tensors)
+
+
+# --------------------------------------------------------------------------- RWKV-6
+@dataclass
+class V6Config:
+    num_layer: int = 2
+    num_emb: int = 256
+    num_hidden: int = 896
+    num_vocab: int = 512
+    head_size: int = 64
+    time_mix: int = 32
+    time_decay: int = 64
+
+    @property
+    def num_head(self) -> int:
+        return self.num_emb // self.head_size
+
+
+V6_CONFIGS: Dict[str, V6Config] = {
+    "tiny": V6Config(2, 256, 896 + 128, 512, 64, 32, 64),
+    "small": V6Config(7, 512, 1792, 1000, 64, 32, 64),           # 7 layers: crosses the rescale-every-6 boundary
+    "7B": V6Config(32, 4096, 14336, 65536, 64, 64, 128),
+}
+
+
+def v6_tensor_plan(cfg: V6Config, seed: int):
+    """GGUF names the reference's map understands for V6 (gguf.rs:1198-1251: attn_* / ffn_* forms)."""
+    D, F, V, H, S, R, W = cfg.num_emb, cfg.num_hidden, cfg.num_vocab, cfg.num_head, cfg.head_size, cfg.time_mix, cfg.time_decay
+
+    def N(name, n, std):
+        return normal(seed, name, n) * np.float32(std)
+
+    def U(name, n, lo, hi):
+        return uniform(seed, name, n) * np.float32(hi - lo) + np.float32(lo)
+
+    yield "token_embd.weight", [D, V], "emb", N("emb", V * D, 1.0)
+    yield "token_embd_norm.weight", [D], "vec", 1.0 + N("ln0.w", D, 0.1)
+    yield "token_embd_norm.bias", [D], "vec", N("ln0.b", D, 0.05)
+    yield "output_norm.weight", [D], "vec", 1.0 + N("lnout.w", D, 0.1)
+    yield "output_norm.bias", [D], "vec", N("lnout.b", D, 0.05)
+    yield "output.weight", [D, V], "head", N("head", V * D, 1.0 / np.sqrt(D))
+    for l in range(cfg.num_layer):
+        p, k = f"blk.{l}.", f"V6L{l}."
+        yield p + "attn_norm.weight", [D], "vec", 1.0 + N(k + "ln1.w", D, 0.1)
+        yield p + "attn_norm.bias", [D], "vec", N(k + "ln1.b", D, 0.05)
+        yield p + "attn_norm_2.weight", [D], "vec", 1.0 + N(k + "ln2.w", D, 0.1)
+        yield p + "attn_norm_2.bias", [D], "vec", N(k + "ln2.b", D, 0.05)
+        yield p + "attn_time_decay", [D], "vec", U(k + "td", D, -3.0, 0.5)
+        yield p + "attn_time_first", [S, H], "vec", N(k + "tf", D, 0.3)
+        for nm in ("x", "w", "k", "v", "r", "g"):
+            yield p + f"attn_time_mix_{nm}", [D], "vec", U(k + "tm" + nm, D, 0.0, 1.0)
+        yield p + "attn_time_mix_w1", [D, 5 * R], "lora", N(k + "tmw1", 5 * R * D, 1.0 / np.sqrt(D))
+        yield p + "attn_time_mix_w2", [R, D, 5], "lora", N(k + "tmw2", 5 * D * R, 0.3 / np.sqrt(R))
+        yield p + "attn_time_decay_w1", [D, W], "lora", N(k + "tdw1", W * D, 1.0 / np.sqrt(D))
+        yield p + "attn_time_decay_w2", [W, D], "lora", N(k + "tdw2", D * W, 0.5 / np.sqrt(W))
+        yield p + "attn_ln_x.weight", [D], "vec", 1.0 + N(k + "lnx.w", D, 0.1)
+        yield p + "attn_ln_x.bias", [D], "vec", N(k + "lnx.b", D, 0.05)
+        for nm in ("k", "v", "r", "g", "output"):
+            yield p + f"attn_{nm}.weight", [D, D], "mat", N(k + "att." + nm, D * D, (0.5 if nm == "k" else 1.0) / np.sqrt(D))
+        yield p + "ffn_time_mix_k", [D], "vec", U(k + "ffn.tmk", D, 0.0, 1.0)
+        yield p + "ffn_time_mix_r", [D], "vec", U(k + "ffn.tmr", D, 0.0, 1.0)
+        yield p + "ffn_k.weight", [D, F], "mat", N(k + "ffn.key", F * D, 1.0 / np.sqrt(D))
+        yield p + "ffn_v.weight", [F, D], "mat", N(k + "ffn.value", D * F, 0.5 / np.sqrt(F))
+        yield p + "ffn_r.weight", [D, D], "mat", N(k + "ffn.rec", D * D, 1.0 / np.sqrt(D))
+
+
+def make_v6_gguf(cfg: V6Config, seed: int = 42, mat: str = "Q5_K", head: str = "Q6_K", emb: str = "F16", lora: str = "F32",
+                 vec: str = "F32", mat_override: Dict[str, str] | None = None) -> bytes:
+    kinds = {"mat": mat, "head": head, "emb": emb, "lora": lora, "vec": vec}
+    tensors = []
+    for name, dims, kind, vals in v6_tensor_plan(cfg, seed):
+        tn = kinds[kind]
+        if mat_override and kind == "mat":
+            for sub, t in mat_override.items():
+                if sub in name:
+                    tn = t
+        tensors.append((name, dims, tn, QUANTIZE[tn](vals.astype(np.float32))))
+    meta = [("general.architecture", "str", "rwkv6"), ("general.alignment", "u32", 32), ("rwkv6.block_count", "u32", cfg.num_layer),
+            ("rwkv6.embedding_length", "u32", cfg.num_emb), ("rwkv6.wkv.head_size", "u32", cfg.head_size)]
+    return write_gguf(meta, tensors)

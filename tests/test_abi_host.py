@@ -119,3 +119,16 @@ def test_redirect_known_answers():
 
 def test_chunk_size_rounding():
     assert _inp([(1, L)], 1).token_chunk_size == 32 and _inp([(1, L)], 33).token_chunk_size == 64
+
+
+def test_host_v6_info_and_tensors_match_oracle():
+    from oracle import rwkv6
+    data = synth.make_v6_gguf(synth.V6_CONFIGS["tiny"], 42)
+    r, oref = wrk.GgufReader(data), ogguf.GgufReader(data)
+    a, b = r.info(), rwkv6.loader_info_v6(oref)
+    assert (a.version, a.num_layer, a.num_emb, a.num_hidden, a.num_vocab, a.num_head) == (6, b.num_layer, b.num_emb, b.num_hidden, b.num_vocab, b.num_head)
+    assert (a.lora_w, a.lora_a) == (b.custom["time_mix"], b.custom["time_decay"])
+    assert r.shape("blocks.0.att.time_mix_w2") == oref.shape("blocks.0.att.time_mix_w2") == [5, 256, 32]
+    for n in ("blocks.1.att.time_mix_w2", "blocks.0.att.time_first", "blocks.1.att.gate.weight", "blocks.0.ffn.time_mix_r"):
+        want = oref.tensor(n)[2].astype(np.float16).astype(np.float32)
+        assert np.array_equal(r.tensor_f16(n).astype(np.float32), want), n

@@ -87,7 +87,7 @@ def test_token_shift_ragged_batches(ctx):
     st = ctx.tensor(state)                                  # [C, 66, B]
     out = ctx.zeros([C, T, 1])
     for row in (0, 65):
-        wrk.TensorOp.token_shift(ctx.buffer(cur), ctx.buffer(mu), st.view(None, row), ctx.tensor(x, [C, T, 1]), out, True)
+        wrk.TensorOp.token_shift(ctx.buffer(cur), ctx.tensor(mu, [C, 1, 1]), st.view(None, row), ctx.tensor(x, [C, T, 1]), out, True)
         prev = np.empty((T, C), np.float32)
         prev[1:] = x[:-1]
         prev[0] = state[0, row]
@@ -95,7 +95,7 @@ def test_token_shift_ragged_batches(ctx):
         want = O.r16(O.mix(x.astype(np.float32), prev, mu.astype(np.float32)[None]))
         close16(out.back().reshape(T, C), want)
     # not reversed: mix(prev, x, mu)
-    wrk.TensorOp.token_shift(ctx.buffer(cur), ctx.buffer(mu), st.view(None, 0), ctx.tensor(x, [C, T, 1]), out, False)
+    wrk.TensorOp.token_shift(ctx.buffer(cur), ctx.tensor(mu, [C, 1, 1]), st.view(None, 0), ctx.tensor(x, [C, T, 1]), out, False)
     prev[0], prev[3] = state[0, 0], state[2, 0]
     close16(out.back().reshape(T, C), O.r16(O.mix(prev, x.astype(np.float32), mu.astype(np.float32)[None])))
 

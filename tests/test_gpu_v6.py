@@ -1,0 +1,125 @@
+"""RWKV-6 path: V6-only ops and whole-model parity against oracle/rwkv6.py.
+PARITY UNPINNED against the real reference (no V6 test or fixture exists there)."""
+import numpy as np
+import pytest
+
+import wrk
+from oracle import gguf as ogguf
+from oracle import rwkv6 as O6
+from oracle import rwkv7 as O
+from oracle import synth
+from oracle.rnn import stack_cursors
+
+pytestmark = pytest.mark.gpu
+LOGIT_TOL, LOGIT_MEAN_TOL = 1e-2, 1.5e-3
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = wrk.Context(0)
+    yield c
+    c.close()
+
+
+def h16(a):
+    return np.asarray(a, np.float32).astype(np.float16)
+
+
+def close16(got, want, ulps=1.0):
+    got, want = np.asarray(got, np.float32), np.asarray(want, np.float32)
+    tol = ulps * np.maximum(np.abs(want), 2.0 ** -14) * 2.0 ** -10 + 1e-6
+    assert np.all(np.abs(got - want) <= tol), np.abs(got - want).max()
+
+
+def test_token_shift_per_token_factors_and_transpose(ctx):
+    """token_shift with a [C, T, 5] factor tensor (v6.rs:804-812) and transpose [R,5,T] -> [R,T,5] (:793)."""
+    C, lens = 256, [3, 2]
+    T, B = sum(lens), 2
+    r = np.random.default_rng(3)
+    x = h16(r.standard_normal((T, C)))
+    fac = h16(r.random((5, T, C)))
+    state = r.standard_normal((B, 66, C)).astype(np.float32)
+    out = ctx.zeros([C, T, 5])
+    wrk.TensorOp.token_shift(ctx.buffer(np.array(stack_cursors(lens), np.uint32)), ctx.tensor(fac), ctx.tensor(state).view(None, 0),
+                             ctx.tensor(x, [C, T, 1]), out, True)
+    prev = np.empty((T, C), np.float32)
+    prev[1:] = x[:-1]
+    prev[0], prev[3] = state[0, 0], state[1, 0]
+    want = O.r16(O.mix(x.astype(np.float32)[None], prev[None], fac.astype(np.float32)))
+    close16(out.back().reshape(5, T, C), want)
+    a = h16(r.standard_normal((T, 5, 32)))
+    t = ctx.zeros([32, T, 5])
+    wrk.TensorOp.transpose(ctx.tensor(a), t)
+    assert np.array_equal(t.back().reshape(5, T, 32), a.transpose(1, 0, 2))
+
+
+@pytest.mark.parametrize("lens,H", [([1], 4), ([4, 0, 3], 4)])
+def test_time_mix_v6(ctx, lens, H):
+    S, B = 64, len(lens)
+    D, T = H * S, sum(lens)
+    r_ = np.random.default_rng(T)
+    k, v, rr = (r_.standard_normal((T, D)).astype(np.float32) * s for s in (0.5, 1.0, 1.0))
+    w = np.exp(-np.exp(r_.uniform(-3, 0.5, (T, D)))).astype(np.float32)
+    u = (0.3 * r_.standard_normal(D)).astype(np.float32)
+    xln = h16(r_.standard_normal((T, D)))
+    state = (0.3 * r_.standard_normal((B, S + 2, D))).astype(np.float32)
+    st, x = ctx.tensor(state), ctx.tensor(xln, [S, H, T])
+    f = lambda a: ctx.tensor(a, [S, H, T])
+    wrk.TensorOp.time_mix_v6(ctx.buffer(np.array(stack_cursors(lens), np.uint32)), f(w), ctx.buffer(u), st.view(None, (0, S + 1)), f(k), f(v), f(rr), x)
+    cur = stack_cursors(lens)
+    want_y, stw = np.empty((T, D), np.float32), state.copy()
+    for t in range(T):
+        b, start, n = cur[t] & 0xFF, (cur[t] >> 8) & 0xFFFF, cur[t] >> 24
+        if t - start + 1 == n:
+            stw[b, 0] = xln[start + n - 1]
+        Sm = stw[b, 1:S + 1].reshape(S, H, S).transpose(1, 0, 2)
+        kv = k[t].reshape(H, S)[:, :, None] * v[t].reshape(H, S)[:, None, :]
+        want_y[t] = np.einsum("hj,hji->hi", rr[t].reshape(H, S), u.reshape(H, S)[:, :, None] * kv + Sm).reshape(D)
+        stw[b, 1:S + 1] = (w[t].reshape(H, S)[:, :, None] * Sm + kv).transpose(1, 0, 2).reshape(S, D)
+    np.testing.assert_allclose(st.back().reshape(B, S + 2, D), stw, rtol=3e-5, atol=3e-5)
+    close16(x.back().reshape(T, D), O.r16(want_y), 2)
+
+
+def test_channel_mix_v6(ctx):
+    C, lens = 256, [2, 3]
+    T = sum(lens)
+    r_ = np.random.default_rng(4)
+    rr, v, x = (h16(r_.standard_normal((T, C))) for _ in range(3))
+    state = r_.standard_normal((2, 66, C)).astype(np.float32)
+    st, xt = ctx.tensor(state), ctx.tensor(x, [C, T, 1])
+    wrk.TensorOp.channel_mix(ctx.buffer(np.array(stack_cursors(lens), np.uint32)), st.view(None, 65), ctx.tensor(rr, [C, T, 1]), ctx.tensor(v, [C, T, 1]), xt)
+    got = st.back().reshape(2, 66, C)
+    assert np.array_equal(got[0, 65], x[1].astype(np.float32)) and np.array_equal(got[1, 65], x[4].astype(np.float32))
+    close16(xt.back().reshape(T, C), O.r16(O.sigmoid(rr.astype(np.float32)) * v.astype(np.float32)), 2)
+
+
+@pytest.mark.parametrize("name,weights,kw", [
+    ("tiny", wrk.WEIGHTS_INLINE, {}),
+    ("tiny", wrk.WEIGHTS_INLINE_F16, {}),
+    ("tiny", wrk.WEIGHTS_INLINE, {"mat": "Q8_0", "head": "F16"}),
+    ("small", wrk.WEIGHTS_INLINE, {"mat": "Q4_K"}),          # 7 layers: rescale-by-half after layer 6 + discounted w_o / ffn.value
+])
+def test_v6_prefill_then_greedy_decode(ctx, name, weights, kw):
+    data = synth.make_v6_gguf(synth.V6_CONFIGS[name], 42, **kw)
+    rt = wrk.Runtime(ctx, wrk.GgufReader(data), num_batch=2, weights=weights)
+    assert rt.info.version == 6
+    oracle = O6.V6Runtime(O6.build_v6(ogguf.GgufReader(data), weights_f16=(weights != wrk.WEIGHTS_INLINE)), 2, act_f16=True)
+    V = rt.info.num_vocab
+    p0, p1 = synth.tokens(3, "v6a", 19, V), synth.tokens(3, "v6b", 5, V)
+    got = rt.infer(wrk.RnnInput([p0, p1], 32))
+    want = oracle.infer_chunk([p0, p1], [18, 23])
+    toks = []
+    for b in range(2):
+        d = np.abs(got[b][0] - want[b])
+        assert d.max() <= LOGIT_TOL and d.mean() <= LOGIT_MEAN_TOL, (b, d.max(), d.mean())
+        toks.append(int(want[b].argmax()))
+        assert int(got[b][0].argmax()) == toks[b]
+    gen, ms = rt.generate_greedy(toks, 8)
+    for step in range(8):
+        ol = oracle.infer_chunk([[toks[0]], [toks[1]]], [0, 1])
+        toks = [int(ol[0].argmax()), int(ol[1].argmax())]
+        assert gen[step].tolist() == toks
+    for b in range(2):
+        d = np.abs(rt.state_back(b) - oracle.state[:, b])
+        assert d.max() <= 2e-2 * max(1.0, float(np.abs(oracle.state).max())) and d.mean() <= 1e-3
+    rt.close()

@@ -354,18 +354,66 @@ int32_t wrk_op_l2_norm(wrk_ctx* ctx, const wrk_tensor* x, float eps) {
     return WRK_OK;
 }
 
-int32_t wrk_op_token_shift(wrk_ctx* ctx, const wrk_buf* cursors, const wrk_buf* time_mix, const wrk_tensor* state,
+int32_t wrk_op_token_shift(wrk_ctx* ctx, const wrk_buf* cursors, const wrk_tensor* time_mix, const wrk_tensor* state,
                            const wrk_tensor* input, const wrk_tensor* output, int32_t reversed) {
     ENTER(ctx);
+    CHECK_T(time_mix, "token_shift time_mix");
     CHECK_T(state, "token_shift state");
     CHECK_T(input, "token_shift input");
     CHECK_T(output, "token_shift output");
-    WRK_ARG(ctx, SAME_SHAPE(input, output), "token_shift: input/output shape mismatch");
+    WRK_ARG(ctx, input->view.shape[0] == output->view.shape[0] && input->view.shape[1] == output->view.shape[1], "token_shift: input/output shape mismatch");
     WRK_ARG(ctx, input->view.shape[2] == 1, "token_shift: input must be [C, T, 1]");
+    WRK_ARG(ctx, time_mix->view.shape[0] == input->view.shape[0] && (time_mix->view.shape[1] == 1 || time_mix->view.shape[1] == input->view.shape[1]) &&
+                     time_mix->view.shape[2] == output->view.shape[2], "token_shift: time_mix must be [C, 1 or T, I] with I = output.shape[2]");
     WRK_ARG(ctx, state->view.shape[0] == input->view.shape[0] && state->view.shape[1] == 1, "token_shift: state must be [C, 1, B]");
     WRK_ARG(ctx, cursors && cursors->bytes >= (size_t)input->view.shape[1] * 4, "token_shift: cursors must hold T u32");
-    WRK_ARG(ctx, time_mix && time_mix->bytes >= (size_t)input->view.shape[0] * 2, "token_shift: time_mix must hold C f16");
-    wrk::token_shift(ctx->stream, (const uint32_t*)cursors->ptr, time_mix->ptr, make_dtensor(state), make_dtensor(input), make_dtensor(output), reversed);
+    wrk::token_shift(ctx->stream, (const uint32_t*)cursors->ptr, make_dtensor(time_mix), make_dtensor(state), make_dtensor(input), make_dtensor(output), reversed);
+    WRK_LAUNCH_CHECK(ctx);
+    return WRK_OK;
+}
+
+int32_t wrk_op_transpose(wrk_ctx* ctx, const wrk_tensor* input, const wrk_tensor* output) {
+    ENTER(ctx);
+    CHECK_T(input, "transpose input");
+    CHECK_T(output, "transpose output");
+    WRK_ARG(ctx, input->view.shape[0] == output->view.shape[0] && input->view.shape[1] == output->view.shape[2] && input->view.shape[2] == output->view.shape[1],
+            "transpose: output must be [C, B, T] for input [C, T, B]");
+    wrk::transpose(ctx->stream, make_dtensor(input), make_dtensor(output));
+    WRK_LAUNCH_CHECK(ctx);
+    return WRK_OK;
+}
+
+int32_t wrk_op_time_mix_v6(wrk_ctx* ctx, const wrk_buf* cursors, const wrk_tensor* time_decay, const wrk_buf* time_first, const wrk_tensor* state,
+                           const wrk_tensor* k, const wrk_tensor* v, const wrk_tensor* r, const wrk_tensor* x) {
+    ENTER(ctx);
+    CHECK_T(time_decay, "time_mix_v6 time_decay");
+    CHECK_T(state, "time_mix_v6 state");
+    CHECK_T(k, "time_mix_v6 k");
+    CHECK_T(v, "time_mix_v6 v");
+    CHECK_T(r, "time_mix_v6 r");
+    CHECK_T(x, "time_mix_v6 x");
+    const uint32_t S = r->view.shape[0], H = r->view.shape[1], T = r->view.shape[2];
+    WRK_ARG(ctx, S == 64, "time_mix_v6: head size %u unsupported (64 only)", S);
+    WRK_ARG(ctx, SAME_SHAPE(r, k) && SAME_SHAPE(r, v) && SAME_SHAPE(r, x) && SAME_SHAPE(r, time_decay), "time_mix_v6: shape mismatch");
+    WRK_ARG(ctx, state->view.shape[0] == S * H && state->view.shape[1] == S + 1 && state->dtype == WRK_F32, "time_mix_v6: state must be f32 [C, S+1, B]");
+    WRK_ARG(ctx, time_first && time_first->bytes >= (size_t)S * H * 4, "time_mix_v6: time_first must hold S*H f32");
+    WRK_ARG(ctx, cursors && cursors->bytes >= (size_t)T * 4, "time_mix_v6: cursors must hold T u32");
+    wrk::time_mix_v6(ctx->stream, (const uint32_t*)cursors->ptr, make_dtensor(time_decay), time_first->ptr, make_dtensor(state), make_dtensor(k),
+                     make_dtensor(v), make_dtensor(r), make_dtensor(x));
+    WRK_LAUNCH_CHECK(ctx);
+    return WRK_OK;
+}
+
+int32_t wrk_op_channel_mix(wrk_ctx* ctx, const wrk_buf* cursors, const wrk_tensor* state, const wrk_tensor* r, const wrk_tensor* v, const wrk_tensor* x) {
+    ENTER(ctx);
+    CHECK_T(state, "channel_mix state");
+    CHECK_T(r, "channel_mix r");
+    CHECK_T(v, "channel_mix v");
+    CHECK_T(x, "channel_mix x");
+    WRK_ARG(ctx, SAME_SHAPE(v, x) && SAME_SHAPE(r, x), "channel_mix: r/v/x shape mismatch");
+    WRK_ARG(ctx, state->view.shape[0] == x->view.shape[0] && state->view.shape[1] == 1, "channel_mix: state must be [C, 1, B]");
+    WRK_ARG(ctx, cursors && cursors->bytes >= (size_t)x->view.shape[1] * 4, "channel_mix: cursors must hold T u32");
+    wrk::channel_mix_v6(ctx->stream, (const uint32_t*)cursors->ptr, make_dtensor(state), make_dtensor(r), make_dtensor(v), make_dtensor(x));
     WRK_LAUNCH_CHECK(ctx);
     return WRK_OK;
 }

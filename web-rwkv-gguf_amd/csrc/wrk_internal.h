@@ -129,7 +129,10 @@ namespace wrk {
 void layer_norm(hipStream_t s, const void* w, const void* b, DTensor x, float eps);
 void group_norm(hipStream_t s, const void* w, const void* b, DTensor x, float eps);
 void l2_norm(hipStream_t s, DTensor x, float eps);
-void token_shift(hipStream_t s, const uint32_t* cursors, const void* mix, DTensor state, DTensor in, DTensor out, int reversed);
+void token_shift(hipStream_t s, const uint32_t* cursors, DTensor mix, DTensor state, DTensor in, DTensor out, int reversed);
+void transpose(hipStream_t s, DTensor in, DTensor out);
+void time_mix_v6(hipStream_t s, const uint32_t* cursors, DTensor decay, const void* u_f32, DTensor state, DTensor k, DTensor v, DTensor r, DTensor x);
+void channel_mix_v6(hipStream_t s, const uint32_t* cursors, DTensor state, DTensor r, DTensor v, DTensor x);
 void binary(hipStream_t s, int is_mul, DTensor in, DTensor out, uint32_t ax, uint32_t ay, uint32_t ao);
 void lerp(hipStream_t s, DTensor x, DTensor y, DTensor f, int reversed);
 void blit(hipStream_t s, DTensor in, DTensor out);

@@ -63,25 +63,27 @@ void l2_norm(hipStream_t s, DTensor x, float eps) {
 }
 
 // ------------------------------------------------------------------ token_shift (token_shift.wgsl:85-117)
-__global__ void __launch_bounds__(256) token_shift_kernel(const uint32_t* __restrict__ cursors, const f16* __restrict__ mixw,
-                                                           DTensor st, DTensor in, DTensor out, int reversed) {
+// mix is [C, A?, I]: one factor vector (A? == 1) or one per stacked token (V6's data-dependent shift), and I
+// outputs per call (count axis = blockIdx.z), written to out [C, T, I].
+__global__ void __launch_bounds__(256) token_shift_kernel(const uint32_t* __restrict__ cursors, DTensor mixw, DTensor st, DTensor in,
+                                                           DTensor out, int reversed) {
     const uint32_t C = in.shape[0];
     const uint32_t c = blockIdx.x * 256 + threadIdx.x;
-    const uint32_t stack = blockIdx.y;
+    const uint32_t stack = blockIdx.y, count = blockIdx.z;
     if (c >= C) return;
     const Cursor cur = unpack_cursor(cursors[stack]);
-    const float f = (float)mixw[c];
+    const float f = dt_load(mixw, dt_index(mixw, c, mixw.shape[1] == 1 ? 0 : stack, count));
     const float xt = dt_load(in, dt_index(in, c, stack, 0));
     const float prev = (stack == cur.token) ? dt_load(st, dt_index(st, c, 0, cur.batch))
                                             : dt_load(in, dt_index(in, c, stack - 1, 0));
     const float v = reversed ? wgsl_mix(xt, prev, f) : wgsl_mix(prev, xt, f);
-    dt_store(out, dt_index(out, c, stack, 0), v);
+    dt_store(out, dt_index(out, c, stack, count), v);
 }
 
-void token_shift(hipStream_t s, const uint32_t* cursors, const void* mixw, DTensor st, DTensor in, DTensor out, int reversed) {
+void token_shift(hipStream_t s, const uint32_t* cursors, DTensor mixw, DTensor st, DTensor in, DTensor out, int reversed) {
     if (in.shape[1] == 0) return;
-    dim3 grid((in.shape[0] + 255) / 256, in.shape[1]);
-    token_shift_kernel<<<grid, 256, 0, s>>>(cursors, (const f16*)mixw, st, in, out, reversed);
+    dim3 grid((in.shape[0] + 255) / 256, in.shape[1], out.shape[2] ? out.shape[2] : 1);
+    token_shift_kernel<<<grid, 256, 0, s>>>(cursors, mixw, st, in, out, reversed);
 }
 
 // ------------------------------------------------------------------ add / mul (binary.wgsl:38-78)
@@ -281,6 +283,89 @@ void channel_mix_v7(hipStream_t s, const uint32_t* cursors, DTensor st, DTensor 
     if (x.shape[1] == 0) return;
     dim3 grid((x.shape[0] + 255) / 256, x.shape[1]);
     channel_mix_v7_kernel<<<grid, 256, 0, s>>>(cursors, st, v, x);
+}
+
+// ------------------------------------------------------------------ transpose (reshape.wgsl:59-78): out[c, b, t] = in[c, t, b]
+__global__ void __launch_bounds__(256) transpose_kernel(DTensor in, DTensor out) {
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= out.shape[0]) return;
+    dt_store(out, dt_index(out, c, blockIdx.z, blockIdx.y), dt_load(in, dt_index(in, c, blockIdx.y, blockIdx.z)));
+}
+
+void transpose(hipStream_t s, DTensor in, DTensor out) {
+    if (in.shape[1] == 0 || in.shape[2] == 0) return;
+    dim3 grid((in.shape[0] + 255) / 256, in.shape[1], in.shape[2]);
+    transpose_kernel<<<grid, 256, 0, s>>>(in, out);
+}
+
+// ------------------------------------------------------------------ time_mix_v6 (time_mix_v6.wgsl:83-155)
+//   y[i]   = sum_j r[j] * (u[j] * k[j] * v[i] + S[j,i]);   S[j,i] <- w[j] * S[j,i] + k[j] * v[i]
+// Same decomposition as time_mix_v7_kernel: one workgroup per (head, sequence chunk), state in registers.
+__global__ void __launch_bounds__(256) time_mix_v6_kernel(const uint32_t* __restrict__ cursors, DTensor decay, const float* __restrict__ u,
+                                                           DTensor st, DTensor k, DTensor v, DTensor r, DTensor x) {
+    constexpr int S = 64;
+    __shared__ float sh_r[S], sh_w[S], sh_k[S], sh_u[S];
+    __shared__ float sh_red[4][S];
+    const uint32_t head = blockIdx.x, t0 = blockIdx.y;
+    const Cursor cur = unpack_cursor(cursors[t0]);
+    if (cur.token != t0) return;
+    const uint32_t tid = threadIdx.x, i = tid & 63, g = tid >> 6;
+    const uint32_t ch = head * S + i;
+    if (g == 0) {
+        const uint32_t last = cur.token + cur.len - 1;
+        dt_store(st, dt_index(st, ch, 0, cur.batch), dt_load(x, dt_index(x, i, head, last)));
+        sh_u[i] = u[ch];
+    }
+    float Sreg[16];
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) Sreg[jj] = dt_load(st, dt_index(st, ch, 1 + g * 16 + jj, cur.batch));
+    for (uint32_t t = cur.token; t < cur.token + cur.len; ++t) {
+        __syncthreads();
+        if (g == 0) {
+            sh_r[i] = dt_load(r, dt_index(r, i, head, t));
+            sh_k[i] = dt_load(k, dt_index(k, i, head, t));
+            sh_w[i] = dt_load(decay, dt_index(decay, i, head, t));
+        }
+        __syncthreads();
+        const float vv = dt_load(v, dt_index(v, i, head, t));
+        float y = 0.0f;
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) {
+            const int j = g * 16 + jj;
+            const float kv = sh_k[j] * vv;
+            y += sh_r[j] * __builtin_fmaf(sh_u[j], kv, Sreg[jj]);
+            Sreg[jj] = __builtin_fmaf(sh_w[j], Sreg[jj], kv);
+        }
+        sh_red[g][i] = y;
+        __syncthreads();
+        if (g == 0) dt_store(x, dt_index(x, i, head, t), (sh_red[0][i] + sh_red[1][i]) + (sh_red[2][i] + sh_red[3][i]));
+    }
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) dt_store(st, dt_index(st, ch, 1 + g * 16 + jj, cur.batch), Sreg[jj]);
+}
+
+void time_mix_v6(hipStream_t s, const uint32_t* cursors, DTensor decay, const void* u, DTensor st, DTensor k, DTensor v, DTensor r, DTensor x) {
+    if (r.shape[2] == 0) return;
+    dim3 grid(r.shape[1], r.shape[2]);
+    time_mix_v6_kernel<<<grid, 256, 0, s>>>(cursors, decay, (const float*)u, st, k, v, r, x);
+}
+
+// ------------------------------------------------------------------ channel_mix (V6) (channel_mix.wgsl:83-107): x <- sigmoid(r) * v
+__global__ void __launch_bounds__(256) channel_mix_v6_kernel(const uint32_t* __restrict__ cursors, DTensor st, DTensor r, DTensor v, DTensor x) {
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t stack = blockIdx.y;
+    if (c >= x.shape[0]) return;
+    const Cursor cur = unpack_cursor(cursors[stack]);
+    const size_t o = dt_index(x, c, stack, 0);
+    if (stack - cur.token + 1 == cur.len) dt_store(st, dt_index(st, c, 0, cur.batch), dt_load(x, o));
+    const float rr = 1.0f / (1.0f + __expf(-dt_load(r, dt_index(r, c, stack, 0))));
+    dt_store(x, o, rr * dt_load(v, dt_index(v, c, stack, 0)));
+}
+
+void channel_mix_v6(hipStream_t s, const uint32_t* cursors, DTensor st, DTensor r, DTensor v, DTensor x) {
+    if (x.shape[1] == 0) return;
+    dim3 grid((x.shape[0] + 255) / 256, x.shape[1]);
+    channel_mix_v6_kernel<<<grid, 256, 0, s>>>(cursors, st, r, v, x);
 }
 
 // ------------------------------------------------------------------ softmax (softmax.wgsl) -- next (f)1

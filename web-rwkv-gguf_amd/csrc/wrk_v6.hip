@@ -1,0 +1,371 @@
+// RWKV-6 model runner behind wrk_v6_* (include/wrk_hip.h): the TensorOp list of v6::Bundle::dispatch
+// (src/runtime/v6.rs:590-699, dispatch_layer :701-958, dispatch_header :960-993), one kernel per reference op,
+// matrices through the inline-dequant matvec / MFMA GEMM.  Buffer dtypes follow Runtime<f16> (v6.rs:265-300):
+// att_k, att_v, att_r and time_decay are f32, everything else f16.
+#include "wrk_internal.h"
+#include "wrk_v7.h"
+
+#define LOCK(ctx) std::lock_guard<std::recursive_mutex> _lk((ctx)->mu)
+
+static constexpr float LN_EPS = 1.0e-5f;    // v6.rs:46
+static constexpr float GN_EPS = 64.0e-5f;   // v6.rs:47
+
+struct V6Scratch {
+    void *input, *x, *aux_x, *att_x, *att_xx, *att_sx, *att_w, *att_g, *att_o, *tmx, *tmt, *tm, *ffn_x, *ffn_kx, *ffn_rx, *ffn_k, *ffn_v, *ffn_r, *head_x;
+    float *att_k, *att_v, *att_r, *time_decay, *head_o;
+    uint32_t *cursors, *tokens, *headers, *argmax, *counter;
+};
+
+struct wrk_v6_model {
+    wrk_ctx* ctx = nullptr;
+    wrk_v6_model_desc d{};
+    std::vector<wrk_v6_layer_desc> layers;
+    void* scratch = nullptr;
+    uint32_t scratch_tokens = 0, scratch_headers = 0;
+    V6Scratch s{};
+    uint32_t* history = nullptr;
+    size_t history_cap = 0;
+    std::map<std::pair<const void*, uint32_t>, wrk_program*> graphs;
+
+    void drop_graphs() { for (auto& kv : graphs) wrk_program_destroy(kv.second); graphs.clear(); }
+    int32_t ensure_scratch(uint32_t T, uint32_t NH);
+    int32_t ensure_history(size_t n);
+    int32_t enqueue_ops(wrk_v7_state* st, uint32_t T, uint32_t NH, bool identity);
+};
+
+static inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+int32_t wrk_v6_model::ensure_scratch(uint32_t T, uint32_t NH) {
+    if (T <= scratch_tokens && NH <= scratch_headers && scratch) return WRK_OK;
+    if (ctx->capturing) return wrk_fail(ctx, WRK_E_ARG, "scratch must be sized before capture");
+    const uint32_t nt = T > scratch_tokens ? T : scratch_tokens, nh = NH > scratch_headers ? NH : scratch_headers;
+    WRK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    drop_graphs();
+    if (scratch) hipFree(scratch);
+    scratch = nullptr;
+    const size_t D = d.num_emb, F = d.num_hidden, V = d.num_vocab, R = d.time_mix, W = d.time_decay;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += up256(bytes); return o; };
+    const size_t v16 = D * nt * 2, v32 = D * nt * 4;
+    const size_t o_input = take(v16), o_x = take(v16), o_aux = take(v16), o_attx = take(v16), o_attxx = take(v16), o_sx = take(v16 * 5);
+    const size_t o_w = take(W * nt * 2), o_g = take(v16), o_o = take(v16), o_tmx = take(R * 5 * nt * 2), o_tmt = take(R * 5 * nt * 2), o_tm = take(v16 * 5);
+    const size_t o_fx = take(v16), o_fkx = take(v16), o_frx = take(v16), o_fk = take(F * nt * 2), o_fv = take(v16), o_fr = take(v16);
+    const size_t o_k = take(v32), o_v = take(v32), o_r = take(v32), o_td = take(v32);
+    const size_t o_hx = take(D * nh * 2), o_ho = take(V * nh * 4);
+    const size_t o_cur = take((size_t)nt * 4), o_tok = take((size_t)nt * 4), o_hdr = take((size_t)nh * 4), o_arg = take((size_t)nh * 4), o_cnt = take(256);
+    WRK_HIP(ctx, hipMalloc(&scratch, off));
+    WRK_HIP(ctx, hipMemsetAsync(scratch, 0, off, ctx->stream));
+    char* b = (char*)scratch;
+    s.input = b + o_input; s.x = b + o_x; s.aux_x = b + o_aux; s.att_x = b + o_attx; s.att_xx = b + o_attxx; s.att_sx = b + o_sx;
+    s.att_w = b + o_w; s.att_g = b + o_g; s.att_o = b + o_o; s.tmx = b + o_tmx; s.tmt = b + o_tmt; s.tm = b + o_tm;
+    s.ffn_x = b + o_fx; s.ffn_kx = b + o_fkx; s.ffn_rx = b + o_frx; s.ffn_k = b + o_fk; s.ffn_v = b + o_fv; s.ffn_r = b + o_fr;
+    s.att_k = (float*)(b + o_k); s.att_v = (float*)(b + o_v); s.att_r = (float*)(b + o_r); s.time_decay = (float*)(b + o_td);
+    s.head_x = b + o_hx; s.head_o = (float*)(b + o_ho);
+    s.cursors = (uint32_t*)(b + o_cur); s.tokens = (uint32_t*)(b + o_tok); s.headers = (uint32_t*)(b + o_hdr); s.argmax = (uint32_t*)(b + o_arg);
+    s.counter = (uint32_t*)(b + o_cnt);
+    scratch_tokens = nt; scratch_headers = nh;
+    const size_t kmax = F > D ? F : D, need = (size_t)nt * (kmax / 32 + 1);
+    if (nt >= 16 && need > ctx->xsum_cap) {
+        if (ctx->xsum) hipFree(ctx->xsum);
+        ctx->xsum = nullptr; ctx->xsum_cap = 0;
+        WRK_HIP(ctx, hipMalloc((void**)&ctx->xsum, need * 4));
+        ctx->xsum_cap = need;
+    }
+    return WRK_OK;
+}
+
+int32_t wrk_v6_model::ensure_history(size_t n) {
+    if (n <= history_cap && history) return WRK_OK;
+    WRK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    drop_graphs();
+    if (history) hipFree(history);
+    history = nullptr;
+    WRK_HIP(ctx, hipMalloc((void**)&history, n * 4 + 256));
+    history_cap = n;
+    return WRK_OK;
+}
+
+static int32_t mm6(wrk_ctx* ctx, const wrk_matrix* m, DTensor in, DTensor out, uint32_t act) {
+    wrk::MatJob j{m->data, m->aux, m->kind, m->flags, m->k, m->m, (uint32_t)m->row_bytes, in, out, act, 0};
+    int rc = -2;
+    if (in.shape[1] * in.shape[2] >= 16) rc = wrk::matmul_mfma(ctx->stream, j, ctx->num_cu, ctx->xsum, ctx->xsum_cap);
+    if (rc == -2) rc = wrk::matvec(ctx->stream, &j, 1, ctx->num_cu);
+    if (rc != 0) return wrk_fail(ctx, WRK_E_ARG, "matmul launch rejected (K=%u M=%u rc=%d)", m->k, m->m, rc);
+    return WRK_OK;
+}
+#define MM(...) do { int32_t _r = mm6(ctx, __VA_ARGS__); if (_r != WRK_OK) return _r; } while (0)
+
+int32_t wrk_v6_model::enqueue_ops(wrk_v7_state* st, uint32_t T, uint32_t NH, bool identity) {
+    hipStream_t q = ctx->stream;
+    const uint32_t D = d.num_emb, F = d.num_hidden, H = d.num_head, S = D / H, V = d.num_vocab, R = d.time_mix, W = d.time_decay;
+    auto vec = [&](void* p, uint32_t c = 0, uint32_t dt = WRK_F16) { return make_dense(p, dt, c ? c : D, T); };
+    auto heads = [&](void* p, uint32_t dt = WRK_F16) { return make_dense(p, dt, S, H, T); };
+    auto bvec = [&](const wrk_buf* b) { return make_dense(b->ptr, WRK_F16, D, 1, 1); };
+    DTensor x = vec(s.x), att_x = vec(s.att_x), att_xx = vec(s.att_xx), aux_x = vec(s.aux_x), att_g = vec(s.att_g), att_o = vec(s.att_o);
+    DTensor att_k = vec(s.att_k, 0, WRK_F32), att_v = vec(s.att_v, 0, WRK_F32), att_r = vec(s.att_r, 0, WRK_F32), tdec = vec(s.time_decay, 0, WRK_F32);
+    DTensor att_w = vec(s.att_w, W), ffn_x = vec(s.ffn_x), ffn_kx = vec(s.ffn_kx), ffn_rx = vec(s.ffn_rx), ffn_k = vec(s.ffn_k, F), ffn_v = vec(s.ffn_v), ffn_r = vec(s.ffn_r);
+    DTensor sx5 = make_dense(s.att_sx, WRK_F16, D, T, 5), tm5 = make_dense(s.tm, WRK_F16, D, T, 5);
+    auto slice = [&](DTensor t, uint32_t i) { t.shape[2] = 1; t.offset[2] = i; return t; };
+
+    DTensor input = vec(s.input);
+    wrk::layer_norm(q, d.ln0_w->ptr, d.ln0_b->ptr, input, LN_EPS);
+    wrk::blit(q, input, x);
+    for (uint32_t li = 0; li < d.num_layer; ++li) {
+        const wrk_v6_layer_desc& L = layers[li];
+        DTensor st_att = make_dense(st->layer_ptr(li), WRK_F32, D, S + 2, st->num_batch);
+        st_att.shape[1] = S + 1;
+        DTensor st_row0 = st_att; st_row0.shape[1] = 1;
+        DTensor st_ffn = make_dense(st->layer_ptr(li), WRK_F32, D, S + 2, st->num_batch);
+        st_ffn.shape[1] = 1; st_ffn.offset[1] = S + 1;
+
+        wrk::blit(q, x, att_x);
+        wrk::layer_norm(q, L.ln1_w->ptr, L.ln1_b->ptr, att_x, LN_EPS);
+        wrk::token_shift(q, s.cursors, bvec(L.time_mix_x), st_row0, att_x, att_xx, 1);
+        MM(L.time_mix_w1, att_xx, make_dense(s.tmx, WRK_F16, R * 5, T), WRK_ACT_TANH);                     // time_mix_x [R, 5, T] seen as [5R, T]
+        wrk::transpose(q, make_dense(s.tmx, WRK_F16, R, 5, T), make_dense(s.tmt, WRK_F16, R, T, 5));
+        for (uint32_t i = 0; i < 5; ++i)                                                                  // batched [R, D, 5] matmul
+            MM(L.time_mix_w2[i], slice(make_dense(s.tmt, WRK_F16, R, T, 5), i), slice(tm5, i), WRK_ACT_NONE);
+        wrk::binary(q, 0, make_dense(L.time_mix->ptr, WRK_F16, D, 1, 5), tm5, 0, 0, 0);                    // add(time_mix, buffer.time_mix)
+        wrk::token_shift(q, s.cursors, tm5, st_row0, att_x, sx5, 1);
+        MM(L.w_k, slice(sx5, 1), att_k, WRK_ACT_NONE);
+        MM(L.w_v, slice(sx5, 2), att_v, WRK_ACT_NONE);
+        MM(L.w_r, slice(sx5, 3), att_r, WRK_ACT_NONE);
+        MM(L.w_g, slice(sx5, 4), att_g, WRK_ACT_NONE);
+        MM(L.time_decay_w1, slice(sx5, 0), att_w, WRK_ACT_TANH);
+        MM(L.time_decay_w2, att_w, tdec, WRK_ACT_NONE);
+        wrk::binary(q, 0, bvec(L.time_decay), tdec, 0, 0, 0);
+        wrk::activate(q, tdec, WRK_ACT_STABLE_EXP);
+        wrk::blit(q, att_x, aux_x);
+        wrk::time_mix_v6(q, s.cursors, heads(s.time_decay, WRK_F32), L.time_first->ptr, st_att, heads(s.att_k, WRK_F32), heads(s.att_v, WRK_F32),
+                         heads(s.att_r, WRK_F32), heads(s.aux_x));
+        wrk::group_norm(q, L.gn_w->ptr, L.gn_b->ptr, heads(s.aux_x), GN_EPS);
+        wrk::blit(q, aux_x, att_x);
+        wrk::binary(q, 1, att_g, att_x, WRK_ACT_SILU, 0, 0);                                              // mul_activate(att_g Silu, att_x)
+        MM(L.w_o, att_x, att_o, WRK_ACT_NONE);
+        wrk::binary(q, 0, att_o, x, 0, 0, 0);
+
+        wrk::blit(q, x, ffn_x);
+        wrk::layer_norm(q, L.ln2_w->ptr, L.ln2_b->ptr, ffn_x, LN_EPS);
+        wrk::token_shift(q, s.cursors, bvec(L.ffn_mix_k), st_ffn, ffn_x, ffn_kx, 1);
+        wrk::token_shift(q, s.cursors, bvec(L.ffn_mix_r), st_ffn, ffn_x, ffn_rx, 1);
+        MM(L.ffn_w_k, ffn_kx, ffn_k, WRK_ACT_SQUARED_RELU);
+        MM(L.ffn_w_v, ffn_k, ffn_v, WRK_ACT_NONE);
+        MM(L.ffn_w_r, ffn_rx, ffn_r, WRK_ACT_NONE);
+        wrk::channel_mix_v6(q, s.cursors, st_ffn, ffn_r, ffn_v, ffn_x);
+        wrk::binary(q, 0, ffn_x, x, 0, 0, 0);
+        if ((li + 1) % d.rescale == 0) wrk::affine(q, x, 0.5f, 0.0f);                                     // v6.rs:953-955
+    }
+    if (NH > 0) {
+        DTensor head_x = make_dense(s.head_x, WRK_F16, D, NH);
+        if (identity) wrk::blit(q, make_dense(s.x, WRK_F16, D, NH), head_x);
+        else wrk::gather_rows_any(q, x, s.headers, head_x, NH);
+        wrk::layer_norm(q, d.ln_out_w->ptr, d.ln_out_b->ptr, head_x, LN_EPS);
+        MM(d.head, head_x, make_dense(s.head_o, WRK_F32, V, NH), WRK_ACT_NONE);
+    }
+    WRK_LAUNCH_CHECK(ctx);
+    return WRK_OK;
+}
+
+static void for_each_handle(wrk_v6_model* m, void (*fb)(const wrk_buf*), void (*fm)(const wrk_matrix*)) {
+    fb(m->d.ln0_w); fb(m->d.ln0_b); fb(m->d.ln_out_w); fb(m->d.ln_out_b); fb(m->d.emb_f16); fm(m->d.head);
+    for (auto& L : m->layers) {
+        const wrk_buf* vecs[] = {L.ln1_w, L.ln1_b, L.ln2_w, L.ln2_b, L.time_decay, L.time_first, L.time_mix_x, L.time_mix, L.gn_w, L.gn_b, L.ffn_mix_k, L.ffn_mix_r};
+        for (const wrk_buf* b : vecs) fb(b);
+        const wrk_matrix* mats[] = {L.time_decay_w1, L.time_decay_w2, L.time_mix_w1, L.time_mix_w2[0], L.time_mix_w2[1], L.time_mix_w2[2], L.time_mix_w2[3],
+                                    L.time_mix_w2[4], L.w_k, L.w_v, L.w_r, L.w_g, L.w_o, L.ffn_w_k, L.ffn_w_v, L.ffn_w_r};
+        for (const wrk_matrix* x : mats) fm(x);
+    }
+}
+
+extern "C" {
+
+int32_t wrk_v6_model_create(wrk_ctx* ctx, const wrk_v6_model_desc* desc, wrk_v6_model** out) {
+    if (!ctx || !desc || !out) return WRK_E_ARG;
+    LOCK(ctx);
+    *out = nullptr;
+    WRK_ARG(ctx, desc->num_layer >= 1 && desc->num_head >= 1 && desc->num_emb % desc->num_head == 0 && desc->num_emb / desc->num_head == 64, "bad model dims (head size must be 64)");
+    WRK_ARG(ctx, desc->layers && desc->head && desc->ln0_w && desc->ln0_b && desc->ln_out_w && desc->ln_out_b, "missing tensors");
+    WRK_ARG(ctx, desc->head->k == desc->num_emb && desc->head->m >= desc->num_vocab, "head matrix shape mismatch");
+    const uint32_t D = desc->num_emb, F = desc->num_hidden, R = desc->time_mix, W = desc->time_decay;
+    for (uint32_t l = 0; l < desc->num_layer; ++l) {
+        const wrk_v6_layer_desc& L = desc->layers[l];
+        const wrk_buf* vecs[] = {L.ln1_w, L.ln1_b, L.ln2_w, L.ln2_b, L.time_decay, L.time_mix_x, L.gn_w, L.gn_b, L.ffn_mix_k, L.ffn_mix_r};
+        for (const wrk_buf* b : vecs) WRK_ARG(ctx, b && b->bytes >= (size_t)D * 2, "layer %u: vector missing or shorter than D f16", l);
+        WRK_ARG(ctx, L.time_first && L.time_first->bytes >= (size_t)D * 4, "layer %u: time_first must hold D f32", l);
+        WRK_ARG(ctx, L.time_mix && L.time_mix->bytes >= (size_t)D * 5 * 2, "layer %u: time_mix must hold 5*D f16", l);
+        struct { const wrk_matrix* m; uint32_t k, mm; } mats[] = {
+            {L.time_decay_w1, D, W}, {L.time_decay_w2, W, D}, {L.time_mix_w1, D, 5 * R}, {L.time_mix_w2[0], R, D}, {L.time_mix_w2[1], R, D},
+            {L.time_mix_w2[2], R, D}, {L.time_mix_w2[3], R, D}, {L.time_mix_w2[4], R, D}, {L.w_k, D, D}, {L.w_v, D, D}, {L.w_r, D, D}, {L.w_g, D, D},
+            {L.w_o, D, D}, {L.ffn_w_k, D, F}, {L.ffn_w_v, F, D}, {L.ffn_w_r, D, D}};
+        for (auto& e : mats) WRK_ARG(ctx, e.m && e.m->k == e.k && e.m->m == e.mm, "layer %u: matrix missing or wrong shape (want K=%u M=%u)", l, e.k, e.mm);
+    }
+    wrk_v6_model* m = new wrk_v6_model();
+    m->ctx = ctx;
+    m->d = *desc;
+    m->d.rescale = desc->rescale ? desc->rescale : 6;
+    m->layers.assign(desc->layers, desc->layers + desc->num_layer);
+    m->d.layers = m->layers.data();
+    for_each_handle(m, [](const wrk_buf* b) { if (b) const_cast<wrk_buf*>(b)->refs.fetch_add(1); },
+                    [](const wrk_matrix* x) { if (x) const_cast<wrk_matrix*>(x)->refs.fetch_add(1); });
+    *out = m;
+    return WRK_OK;
+}
+
+int32_t wrk_v6_model_destroy(wrk_v6_model* m) {
+    if (!m) return WRK_E_ARG;
+    {
+        LOCK(m->ctx);
+        hipSetDevice(m->ctx->device);
+        hipStreamSynchronize(m->ctx->stream);
+        m->drop_graphs();
+        if (m->scratch) hipFree(m->scratch);
+        if (m->history) hipFree(m->history);
+    }
+    for_each_handle(m, [](const wrk_buf* b) { if (b) wrk_buf_release(const_cast<wrk_buf*>(b)); },
+                    [](const wrk_matrix* x) { if (x) wrk_matrix_release(const_cast<wrk_matrix*>(x)); });
+    delete m;
+    return WRK_OK;
+}
+
+size_t wrk_v6_model_token_bytes(const wrk_v6_model* m, uint32_t B) {
+    if (!m) return 0;
+    const size_t D = m->d.num_emb, S = D / m->d.num_head, V = m->d.num_vocab;
+    size_t w = wrk_matrix_stream_bytes(m->d.head) + 4 * D * 2;
+    for (auto& L : m->layers) {
+        const wrk_matrix* mats[] = {L.time_decay_w1, L.time_decay_w2, L.time_mix_w1, L.time_mix_w2[0], L.time_mix_w2[1], L.time_mix_w2[2], L.time_mix_w2[3],
+                                    L.time_mix_w2[4], L.w_k, L.w_v, L.w_r, L.w_g, L.w_o, L.ffn_w_k, L.ffn_w_v, L.ffn_w_r};
+        for (const wrk_matrix* x : mats) w += wrk_matrix_stream_bytes(x);
+        w += 16 * D * 2 + D * 4;
+    }
+    return w + 2 * (size_t)m->d.num_layer * D * (S + 2) * 4 * B + (size_t)B * (D * 2 + V * 4);
+}
+
+int32_t wrk_v6_state_create(wrk_ctx* ctx, const wrk_v6_model* model, uint32_t num_batch, wrk_v7_state** out) {
+    if (!ctx || !model || !out) return WRK_E_ARG;
+    LOCK(ctx);
+    *out = nullptr;
+    WRK_ARG(ctx, num_batch >= 1 && num_batch <= 255, "num_batch must be 1..255");
+    WRK_HIP(ctx, hipSetDevice(ctx->device));
+    wrk_v7_state* st = new wrk_v7_state();
+    st->ctx = ctx; st->num_layer = model->d.num_layer; st->num_emb = model->d.num_emb; st->head_size = 64; st->num_batch = num_batch;
+    const size_t bytes = st->layer_elems() * st->num_layer * 4;
+    hipError_t e = hipMalloc((void**)&st->data, bytes);
+    if (e == hipSuccess) e = hipMemsetAsync(st->data, 0, bytes, ctx->stream);
+    if (e != hipSuccess) { delete st; return wrk_fail(ctx, WRK_E_OOM, "state alloc: %s", hipGetErrorString(e)); }
+    *out = st;
+    return WRK_OK;
+}
+
+int32_t wrk_v6_infer(wrk_ctx* ctx, wrk_v6_model* m, wrk_v7_state* st, const uint32_t* tokens, const uint16_t* emb_rows, const uint32_t* cursors,
+                     uint32_t T, const uint32_t* headers, uint32_t NH, float* logits, uint32_t* argmax, uint32_t) {
+    if (!ctx || !m || !st) return WRK_E_ARG;
+    LOCK(ctx);
+    WRK_HIP(ctx, hipSetDevice(ctx->device));
+    if (T == 0) return WRK_OK;
+    WRK_ARG(ctx, cursors && (tokens || emb_rows) && (!tokens || m->d.emb_f16) && (NH == 0 || headers), "missing inputs");
+    WRK_ARG(ctx, st->num_emb == m->d.num_emb && st->num_layer == m->d.num_layer, "state does not belong to this model");
+    const uint32_t D = m->d.num_emb, V = m->d.num_vocab;
+    std::vector<uint8_t> seen(256, 0);
+    for (uint32_t t = 0; t < T; ++t) {
+        const uint32_t c = cursors[t], b = c & 0xff, tok = (c >> 8) & 0xffff, len = c >> 24;
+        WRK_ARG(ctx, b < st->num_batch, "cursor %u: batch %u >= %u", t, b, st->num_batch);
+        WRK_ARG(ctx, len >= 1 && tok <= t && t < tok + len && tok + len <= T, "cursor %u: bad range", t);
+        if (tok == t) { WRK_ARG(ctx, !seen[b], "cursor %u: batch %u appears twice", t, b); seen[b] = 1; }
+        if (tokens) WRK_ARG(ctx, tokens[t] < V, "token %u: id %u >= vocab %u", t, tokens[t], V);
+    }
+    bool identity = (NH == T);
+    for (uint32_t h = 0; h < NH; ++h) { WRK_ARG(ctx, headers[h] < T, "header %u out of range", h); if (headers[h] != h) identity = false; }
+    int32_t rc = m->ensure_scratch(T, NH ? NH : 1);
+    if (rc != WRK_OK) return rc;
+    rc = wrk_buf_write_raw(ctx, m->s.cursors, cursors, (size_t)T * 4);
+    if (rc == WRK_OK && NH) rc = wrk_buf_write_raw(ctx, m->s.headers, headers, (size_t)NH * 4);
+    if (rc != WRK_OK) return rc;
+    if (tokens) {
+        rc = wrk_buf_write_raw(ctx, m->s.tokens, tokens, (size_t)T * 4);
+        if (rc != WRK_OK) return rc;
+        wrk::gather_rows_f16(ctx->stream, m->d.emb_f16->ptr, m->s.tokens, m->s.input, D, T);
+    } else {
+        rc = wrk_buf_write_raw(ctx, m->s.input, emb_rows, (size_t)T * D * 2);
+        if (rc != WRK_OK) return rc;
+    }
+    rc = m->enqueue_ops(st, T, NH, identity);
+    if (rc != WRK_OK) return rc;
+    if (NH && argmax) wrk::argmax_rows(ctx->stream, m->s.head_o, V, V, NH, m->s.argmax);
+    WRK_LAUNCH_CHECK(ctx);
+    if (NH && logits) WRK_HIP(ctx, hipMemcpyAsync(logits, m->s.head_o, (size_t)NH * V * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (NH && argmax) WRK_HIP(ctx, hipMemcpyAsync(argmax, m->s.argmax, (size_t)NH * 4, hipMemcpyDeviceToHost, ctx->stream));
+    WRK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return WRK_OK;
+}
+
+int32_t wrk_v6_generate_greedy(wrk_ctx* ctx, wrk_v6_model* m, wrk_v7_state* st, const uint32_t* first_tokens, uint32_t B, uint32_t steps,
+                               uint32_t* out_tokens, float* last_logits, float* elapsed_ms, uint32_t) {
+    if (!ctx || !m || !st || !first_tokens) return WRK_E_ARG;
+    LOCK(ctx);
+    WRK_HIP(ctx, hipSetDevice(ctx->device));
+    WRK_ARG(ctx, m->d.emb_f16, "generate_greedy needs the device embedding table");
+    WRK_ARG(ctx, B >= 1 && B <= st->num_batch, "num_batch %u exceeds the state's %u", B, st->num_batch);
+    const uint32_t D = m->d.num_emb, V = m->d.num_vocab;
+    for (uint32_t b = 0; b < B; ++b) WRK_ARG(ctx, first_tokens[b] < V, "first token %u out of vocab", first_tokens[b]);
+    if (elapsed_ms) *elapsed_ms = 0.0f;
+    if (steps == 0) return WRK_OK;
+    int32_t rc = m->ensure_scratch(B, B);
+    if (rc == WRK_OK) rc = m->ensure_history((size_t)steps * B);
+    if (rc != WRK_OK) return rc;
+    std::vector<uint32_t> cur(B), hdr(B);
+    for (uint32_t b = 0; b < B; ++b) { cur[b] = b | (b << 8) | (1u << 24); hdr[b] = b; }
+    rc = wrk_buf_write_raw(ctx, m->s.cursors, cur.data(), (size_t)B * 4);
+    if (rc == WRK_OK) rc = wrk_buf_write_raw(ctx, m->s.headers, hdr.data(), (size_t)B * 4);
+    if (rc == WRK_OK) rc = wrk_buf_write_raw(ctx, m->s.tokens, first_tokens, (size_t)B * 4);
+    if (rc != WRK_OK) return rc;
+    WRK_HIP(ctx, hipMemsetAsync(m->s.counter, 0, 4, ctx->stream));
+    WRK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const char* ng = getenv("WRK_NO_GRAPH");
+    const bool eager = ng && ng[0] == '1';
+    auto enqueue_step = [&]() -> int32_t {
+        wrk::gather_rows_f16(ctx->stream, m->d.emb_f16->ptr, m->s.tokens, m->s.input, D, B);
+        int32_t r = m->enqueue_ops(st, B, B, true);
+        if (r != WRK_OK) return r;
+        wrk::argmax_rows(ctx->stream, m->s.head_o, V, V, B, m->s.argmax);
+        wrk::advance_tokens(ctx->stream, m->s.argmax, m->s.tokens, m->history, m->s.counter, B);
+        return WRK_OK;
+    };
+    wrk_program* prog = nullptr;
+    const auto key = std::make_pair((const void*)st, B);
+    if (!eager) {
+        auto it = m->graphs.find(key);
+        if (it != m->graphs.end()) prog = it->second;
+        else {
+            rc = wrk_capture_begin(ctx);
+            if (rc != WRK_OK) return rc;
+            rc = enqueue_step();
+            wrk_program* p = nullptr;
+            int32_t rc2 = wrk_capture_end(ctx, &p);
+            if (rc != WRK_OK) { if (p) wrk_program_destroy(p); return rc; }
+            if (rc2 != WRK_OK) return rc2;
+            prog = p;
+            m->graphs[key] = prog;
+        }
+    }
+    hipEvent_t e0, e1;
+    WRK_HIP(ctx, hipEventCreate(&e0));
+    WRK_HIP(ctx, hipEventCreate(&e1));
+    WRK_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    for (uint32_t i = 0; i < steps; ++i) {
+        if (eager) { rc = enqueue_step(); if (rc != WRK_OK) return rc; }
+        else WRK_HIP(ctx, hipGraphLaunch(prog->exec, ctx->stream));
+    }
+    WRK_HIP(ctx, hipEventRecord(e1, ctx->stream));
+    WRK_HIP(ctx, hipEventSynchronize(e1));
+    float ms = 0.0f;
+    WRK_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    if (elapsed_ms) *elapsed_ms = ms;
+    if (out_tokens) WRK_HIP(ctx, hipMemcpyAsync(out_tokens, m->history, (size_t)steps * B * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (last_logits) WRK_HIP(ctx, hipMemcpyAsync(last_logits, m->s.head_o, (size_t)B * V * 4, hipMemcpyDeviceToHost, ctx->stream));
+    WRK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return WRK_OK;
+}
+
+}  // extern "C"

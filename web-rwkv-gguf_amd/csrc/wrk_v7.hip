@@ -135,12 +135,12 @@ int32_t wrk_v7_model::enqueue_ops(wrk_v7_state* st, uint32_t T, uint32_t NH, boo
 
         wrk::blit(q, x, att_x);                                                          // 1
         wrk::layer_norm(q, L.ln1_w->ptr, L.ln1_b->ptr, att_x, LN_EPS);                   // 2
-        wrk::token_shift(q, s.cursors, L.x_r->ptr, st_row0, att_x, rx, 1);               // 3
-        wrk::token_shift(q, s.cursors, L.x_w->ptr, st_row0, att_x, wx, 1);
-        wrk::token_shift(q, s.cursors, L.x_k->ptr, st_row0, att_x, kx, 1);
-        wrk::token_shift(q, s.cursors, L.x_v->ptr, st_row0, att_x, vx, 1);
-        wrk::token_shift(q, s.cursors, L.x_a->ptr, st_row0, att_x, ax, 1);
-        wrk::token_shift(q, s.cursors, L.x_g->ptr, st_row0, att_x, gx, 1);
+        wrk::token_shift(q, s.cursors, bvec(L.x_r), st_row0, att_x, rx, 1);               // 3
+        wrk::token_shift(q, s.cursors, bvec(L.x_w), st_row0, att_x, wx, 1);
+        wrk::token_shift(q, s.cursors, bvec(L.x_k), st_row0, att_x, kx, 1);
+        wrk::token_shift(q, s.cursors, bvec(L.x_v), st_row0, att_x, vx, 1);
+        wrk::token_shift(q, s.cursors, bvec(L.x_a), st_row0, att_x, ax, 1);
+        wrk::token_shift(q, s.cursors, bvec(L.x_g), st_row0, att_x, gx, 1);
         MM(L.w_r, rx, r, WRK_ACT_NONE);                                                  // 4
         MM(L.w_k, kx, k, WRK_ACT_NONE);
         MM(L.w_v, vx, v, WRK_ACT_NONE);
@@ -176,7 +176,7 @@ int32_t wrk_v7_model::enqueue_ops(wrk_v7_state* st, uint32_t T, uint32_t NH, boo
         wrk::binary(q, 0, o, x, 0, 0, 0);
         wrk::blit(q, x, ffn_x);                                                          // 17
         wrk::layer_norm(q, L.ln2_w->ptr, L.ln2_b->ptr, ffn_x, LN_EPS);
-        wrk::token_shift(q, s.cursors, L.ffn_x_k->ptr, st_ffn, ffn_x, ffn_kx, 1);        // 18
+        wrk::token_shift(q, s.cursors, bvec(L.ffn_x_k), st_ffn, ffn_x, ffn_kx, 1);        // 18
         MM(L.ffn_w_k, ffn_kx, ffn_k, WRK_ACT_SQUARED_RELU);                              // 19
         MM(L.ffn_w_v, ffn_k, ffn_v, WRK_ACT_NONE);                                       // 20
         wrk::channel_mix_v7(q, s.cursors, st_ffn, ffn_v, ffn_x);                         // 21

@@ -490,12 +490,15 @@ struct wrk_runtime {
     std::vector<wrk_buf*> bufs;
     std::vector<wrk_matrix*> mats;
     std::vector<wrk_v7_layer_desc> layers;
+    std::vector<wrk_v6_layer_desc> layers6;
     wrk_v7_model* model = nullptr;
+    wrk_v6_model* model6 = nullptr;
     wrk_v7_state* state = nullptr;
     uint32_t num_batch = 0;
     ~wrk_runtime() {
         if (state) wrk_v7_state_destroy(state);
         if (model) wrk_v7_model_destroy(model);
+        if (model6) wrk_v6_model_destroy(model6);
         for (auto* m : mats) wrk_matrix_release(m);
         for (auto* b : bufs) wrk_buf_release(b);
     }
@@ -520,22 +523,36 @@ static int32_t loader_info(const wrk_gguf& g, wrk_model_info& out) {            
     if (!g.shape("blocks.0.ffn.key.weight", ffn) || ffn.size() != 2) return fail(WRK_E_ARG, "tensor not found: blocks.0.ffn.key.weight");
     const char* sep[] = {"x_r", "x_w", "x_k", "x_v", "x_a", "x_g", "w0", "w1", "w2", "a0", "a1", "a2", "g1", "g2", "r_k", "k_k", "k_a"};
     const char* fused[] = {"time_maa", "w0", "w1", "w2", "a0", "a1", "a2", "g1", "g2", "r_k", "k_k", "k_a"};
-    bool v7s = true, v7f = true;
+    const char* v6n[] = {"time_mix_x", "time_mix_w", "time_mix_k", "time_mix_v", "time_mix_r", "time_mix_g", "time_mix_w1", "time_mix_w2",
+                         "time_decay_w1", "time_decay_w2"};
+    bool v7s = true, v7f = true, v6 = g.contains("blocks.0.ffn.time_mix_k") && g.contains("blocks.0.ffn.time_mix_r");
     for (const char* s : sep) v7s = v7s && g.contains(std::string("blocks.0.att.") + s);
     for (const char* s : fused) v7f = v7f && g.contains(std::string("blocks.0.att.") + s);
-    if (!(v7s || v7f)) return fail(WRK_E_UNSUPPORTED, "invalid model version (only RWKV-7 is built in this round)");
-    if (!g.shape("blocks.0.att.r_k", rk) || rk.size() != 2) return fail(WRK_E_ARG, "blocks.0.att.r_k: cannot derive num_head (rwkv7.wkv.head_size missing?)");
+    for (const char* s : v6n) v6 = v6 && g.contains(std::string("blocks.0.att.") + s);
     auto rank = [&](const char* n, uint32_t& o) {
         std::vector<size_t> s;
         if (!g.shape(n, s) || s.empty()) return false;
         o = (uint32_t)s[0];
         return true;
     };
-    out.version = 7;
     out.num_layer = num_layer;
     out.num_emb = (uint32_t)embed[1];
     out.num_vocab = (uint32_t)embed[0];
     out.num_hidden = (uint32_t)ffn[0];
+    if (v6 && !(v7s || v7f)) {                                                 // (_, _, true, false) => V6, loader.rs:325-331
+        std::vector<size_t> tf;
+        if (!g.shape("blocks.0.att.time_first", tf) || tf.empty()) return fail(WRK_E_ARG, "tensor not found: blocks.0.att.time_first");
+        out.version = 6;
+        out.num_head = (uint32_t)tf[0];
+        uint32_t w1 = 0;
+        if (!rank("blocks.0.att.time_mix_w1", w1) || !rank("blocks.0.att.time_decay_w1", out.lora_a)) return fail(WRK_E_ARG, "V6 LoRA tensors missing");
+        out.lora_w = w1 / 5;                                                   // CustomInfo::time_mix (loader.rs:345)
+        out.lora_g = out.lora_v = 0;
+        return WRK_OK;
+    }
+    if (!(v7s || v7f)) return fail(WRK_E_UNSUPPORTED, "invalid model version (RWKV-6 and RWKV-7 are built)");
+    if (!g.shape("blocks.0.att.r_k", rk) || rk.size() != 2) return fail(WRK_E_ARG, "blocks.0.att.r_k: cannot derive num_head (rwkv7.wkv.head_size missing?)");
+    out.version = 7;
     out.num_head = (uint32_t)rk[0];
     if (!rank("blocks.0.att.w1", out.lora_w) || !rank("blocks.0.att.a1", out.lora_a) || !rank("blocks.0.att.g1", out.lora_g))
         return fail(WRK_E_ARG, "LoRA tensors missing");
@@ -767,6 +784,92 @@ int32_t wrk_runtime_create(wrk_ctx* ctx, const wrk_gguf* g, const wrk_build_opti
 #define VEC(name, n, dst) do { int32_t _r = vec(name, n, &dst); if (_r != WRK_OK) return _r; } while (0)
 #define MAT(name, k, m, big, disc, dst) do { int32_t _r = mat(name, k, m, big, disc, &dst); if (_r != WRK_OK) return _r; } while (0)
 
+    if (I.version == 6) {
+        // ModelBuilder::build_v6 (v6.rs:995-1170)
+        const uint32_t rescale6 = opt && opt->rescale ? opt->rescale : 6;
+        const uint32_t R = I.lora_w, W = I.lora_a;
+        wrk_v6_model_desc d6{};
+        d6.num_layer = I.num_layer; d6.num_emb = D; d6.num_hidden = I.num_hidden; d6.num_vocab = I.num_vocab; d6.num_head = I.num_head;
+        d6.time_mix = R; d6.time_decay = W; d6.rescale = rescale6;
+        wrk_buf *a, *b6, *c, *e, *emb6;
+        VEC("blocks.0.ln0.weight", D, a); VEC("blocks.0.ln0.bias", D, b6); VEC("ln_out.weight", D, c); VEC("ln_out.bias", D, e);
+        VEC("emb.weight", (size_t)I.num_vocab * D, emb6);
+        wrk_matrix* head6;
+        MAT("head.weight", D, I.num_vocab, true, 1.0f, head6);
+        d6.ln0_w = a; d6.ln0_b = b6; d6.ln_out_w = c; d6.ln_out_b = e; d6.emb_f16 = emb6; d6.head = head6;
+        rt->layers6.resize(I.num_layer);
+        for (uint32_t l = 0; l < I.num_layer; ++l) {
+            wrk_v6_layer_desc& L = rt->layers6[l];
+            const float discount = 1.0f / (float)(1u << std::min<uint32_t>(l / rescale6, 30));
+            const std::string blk = "blocks." + std::to_string(l), att = blk + ".att", ffn = blk + ".ffn";
+            wrk_buf* vb;
+            wrk_matrix* m;
+#define V6(field, name) VEC(name, D, vb); L.field = vb
+#define M6(field, name, k, mm, big, disc) MAT(name, k, mm, big, disc, m); L.field = m
+            V6(ln1_w, blk + ".ln1.weight"); V6(ln1_b, blk + ".ln1.bias"); V6(ln2_w, blk + ".ln2.weight"); V6(ln2_b, blk + ".ln2.bias");
+            V6(time_decay, att + ".time_decay"); V6(time_mix_x, att + ".time_mix_x");
+            {   // load_vector_f32 (loader.rs:443-478): f16-rounded values widened to f32
+                std::vector<uint16_t> h;
+                int32_t r = g->tensor_f16(att + ".time_first", h);
+                if (r != WRK_OK) return r;
+                if (h.size() != D) return fail(WRK_E_ARG, "%s.time_first: %zu elements, expected %u", att.c_str(), h.size(), D);
+                std::vector<float> f(h.size());
+                for (size_t i = 0; i < h.size(); ++i) f[i] = h2f(h[i]);
+                wrk_buf* fb = nullptr;
+                r = wrk_buf_create(ctx, f.size() * 4, f.data(), &fb);
+                if (r != WRK_OK) return fail(r, "upload time_first: %s", wrk_last_error(ctx));
+                rt->bufs.push_back(fb);
+                L.time_first = fb;
+            }
+            {   // time_mix stack [D, 1, 5] = w, k, v, r, g (v6.rs:1054-1071)
+                std::vector<uint16_t> all;
+                for (const char* n : {"w", "k", "v", "r", "g"}) {
+                    std::vector<uint16_t> h;
+                    int32_t r = g->tensor_f16(att + ".time_mix_" + n, h);
+                    if (r != WRK_OK) return r;
+                    if (h.size() != D) return fail(WRK_E_ARG, "%s.time_mix_%s: bad size", att.c_str(), n);
+                    all.insert(all.end(), h.begin(), h.end());
+                }
+                wrk_buf* tb = nullptr;
+                int32_t r = wrk_buf_create(ctx, all.size() * 2, all.data(), &tb);
+                if (r != WRK_OK) return fail(r, "upload time_mix: %s", wrk_last_error(ctx));
+                rt->bufs.push_back(tb);
+                L.time_mix = tb;
+            }
+            M6(time_decay_w1, att + ".time_decay_w1", D, W, false, 1.0f); M6(time_decay_w2, att + ".time_decay_w2", W, D, false, 1.0f);
+            M6(time_mix_w1, att + ".time_mix_w1", D, 5 * R, false, 1.0f);
+            {   // batched time_mix_w2 [R, D, 5] -> five F16 matrices [R -> D]
+                std::vector<size_t> shp;
+                if (!g->shape(att + ".time_mix_w2", shp) || shp.size() != 3 || shp[0] != 5 || shp[1] != D || shp[2] != R)
+                    return fail(WRK_E_ARG, "%s.time_mix_w2: expected shape [5, %u, %u]", att.c_str(), D, R);
+                std::vector<uint16_t> h;
+                int32_t r = g->tensor_f16(att + ".time_mix_w2", h);
+                if (r != WRK_OK) return r;
+                for (int i = 0; i < 5; ++i) {
+                    wrk_matrix* mt = nullptr;
+                    r = wrk_matrix_create(ctx, WRK_MAT_F16, R, D, h.data() + (size_t)i * D * R, (size_t)D * R * 2, WRK_MATRIX_EXACT, &mt);
+                    if (r != WRK_OK) return fail(r, "upload time_mix_w2[%d]: %s", i, wrk_last_error(ctx));
+                    rt->mats.push_back(mt);
+                    L.time_mix_w2[i] = mt;
+                }
+            }
+            V6(gn_w, att + ".ln_x.weight"); V6(gn_b, att + ".ln_x.bias");
+            M6(w_k, att + ".key.weight", D, D, true, 1.0f); M6(w_v, att + ".value.weight", D, D, true, 1.0f);
+            M6(w_r, att + ".receptance.weight", D, D, true, 1.0f); M6(w_g, att + ".gate.weight", D, D, true, 1.0f);
+            M6(w_o, att + ".output.weight", D, D, true, discount);
+            V6(ffn_mix_k, ffn + ".time_mix_k"); V6(ffn_mix_r, ffn + ".time_mix_r");
+            M6(ffn_w_k, ffn + ".key.weight", D, I.num_hidden, true, 1.0f); M6(ffn_w_v, ffn + ".value.weight", I.num_hidden, D, true, discount);
+            M6(ffn_w_r, ffn + ".receptance.weight", D, D, true, 1.0f);
+#undef V6
+#undef M6
+        }
+        d6.layers = rt->layers6.data();
+        HOSTCHK(wrk_v6_model_create(ctx, &d6, &rt->model6));
+        HOSTCHK(wrk_v6_state_create(ctx, rt->model6, num_batch, &rt->state));
+        *out = rt.release();
+        return WRK_OK;
+    }
+
     wrk_v7_model_desc desc{};
     desc.num_layer = I.num_layer; desc.num_emb = D; desc.num_hidden = I.num_hidden; desc.num_vocab = I.num_vocab; desc.num_head = I.num_head;
     desc.lora_w = I.lora_w; desc.lora_a = I.lora_a; desc.lora_g = I.lora_g; desc.lora_v = I.lora_v;
@@ -821,6 +924,7 @@ int32_t wrk_runtime_destroy(wrk_runtime* rt) { delete rt; return WRK_OK; }
 int32_t wrk_runtime_info(const wrk_runtime* rt, wrk_model_info* out) { if (!rt || !out) return WRK_E_ARG; *out = rt->info; return WRK_OK; }
 wrk_v7_model* wrk_runtime_model(wrk_runtime* rt) { return rt ? rt->model : nullptr; }
 wrk_v7_state* wrk_runtime_state(wrk_runtime* rt) { return rt ? rt->state : nullptr; }
+wrk_v6_model* wrk_runtime_model_v6(wrk_runtime* rt) { return rt ? rt->model6 : nullptr; }
 
 // SimpleRuntime::infer (mod.rs:238-263) with RnnJob::{load, submit, back} (v7.rs:434-492)
 int32_t wrk_runtime_infer(wrk_runtime* rt, wrk_rnn_input* in, float* logits, size_t capacity_rows, uint32_t* rows, uint32_t mode) {
@@ -851,9 +955,10 @@ int32_t wrk_runtime_infer(wrk_runtime* rt, wrk_rnn_input* in, float* logits, siz
         }
         token += lens[b];
     }
-    const int32_t rc = wrk_v7_infer(rt->ctx, rt->model, rt->state, toks.data(), nullptr, cursors.data(), T, headers.data(),
-                                    (uint32_t)headers.size(), logits, nullptr, mode);
-    if (rc != WRK_OK) return fail(rc, "wrk_v7_infer: %s", wrk_last_error(rt->ctx));
+    const int32_t rc = rt->model6
+        ? wrk_v6_infer(rt->ctx, rt->model6, rt->state, toks.data(), nullptr, cursors.data(), T, headers.data(), (uint32_t)headers.size(), logits, nullptr, mode)
+        : wrk_v7_infer(rt->ctx, rt->model, rt->state, toks.data(), nullptr, cursors.data(), T, headers.data(), (uint32_t)headers.size(), logits, nullptr, mode);
+    if (rc != WRK_OK) return fail(rc, "infer: %s", wrk_last_error(rt->ctx));
     for (uint32_t b = 0; b < nb; ++b) rows[b] = outputs[b].second - outputs[b].first;
     for (uint32_t b = 0; b < nb; ++b) in->tokens[b].erase(in->tokens[b].begin(), in->tokens[b].begin() + lens[b]);   // input.step()
     return WRK_OK;

@@ -98,7 +98,7 @@ HIP_SYMBOLS = {
     "wrk_op_layer_norm": (C.c_int32, [_P, _P, _P, _TP, C.c_float]),
     "wrk_op_group_norm": (C.c_int32, [_P, _P, _P, _TP, C.c_float]),
     "wrk_op_l2_norm": (C.c_int32, [_P, _TP, C.c_float]),
-    "wrk_op_token_shift": (C.c_int32, [_P, _P, _P, _TP, _TP, _TP, C.c_int32]),
+    "wrk_op_token_shift": (C.c_int32, [_P, _P, _TP, _TP, _TP, _TP, C.c_int32]),
     "wrk_op_add": (C.c_int32, [_P, _TP, _TP, C.c_uint32, C.c_uint32, C.c_uint32]),
     "wrk_op_mul": (C.c_int32, [_P, _TP, _TP, C.c_uint32, C.c_uint32, C.c_uint32]),
     "wrk_op_lerp": (C.c_int32, [_P, _TP, _TP, _TP, C.c_int32]),
@@ -119,6 +119,15 @@ HIP_SYMBOLS = {
     "wrk_v7_state_back": (C.c_int32, [_P, _P, C.c_uint32, _f32p]),
     "wrk_v7_infer": (C.c_int32, [_P, _P, _P, _u32p, C.POINTER(C.c_uint16), _u32p, C.c_uint32, _u32p, C.c_uint32, _f32p, _u32p, C.c_uint32]),
     "wrk_v7_generate_greedy": (C.c_int32, [_P, _P, _P, _u32p, C.c_uint32, C.c_uint32, _u32p, _f32p, _f32p, C.c_uint32]),
+    "wrk_op_transpose": (C.c_int32, [_P, _TP, _TP]),
+    "wrk_op_time_mix_v6": (C.c_int32, [_P, _P, _TP, _P, _TP, _TP, _TP, _TP, _TP]),
+    "wrk_op_channel_mix": (C.c_int32, [_P, _P, _TP, _TP, _TP, _TP]),
+    "wrk_v6_model_create": (C.c_int32, [_P, _P, C.POINTER(_P)]),
+    "wrk_v6_model_destroy": (C.c_int32, [_P]),
+    "wrk_v6_model_token_bytes": (C.c_size_t, [_P, C.c_uint32]),
+    "wrk_v6_state_create": (C.c_int32, [_P, _P, C.c_uint32, C.POINTER(_P)]),
+    "wrk_v6_infer": (C.c_int32, [_P, _P, _P, _u32p, C.POINTER(C.c_uint16), _u32p, C.c_uint32, _u32p, C.c_uint32, _f32p, _u32p, C.c_uint32]),
+    "wrk_v6_generate_greedy": (C.c_int32, [_P, _P, _P, _u32p, C.c_uint32, C.c_uint32, _u32p, _f32p, _f32p, C.c_uint32]),
 }
 RT_SYMBOLS = {
     "wrk_host_last_error": (C.c_char_p, []),
@@ -149,6 +158,7 @@ RT_SYMBOLS = {
     "wrk_runtime_info": (C.c_int32, [_P, C.POINTER(ModelInfo)]),
     "wrk_runtime_model": (_P, [_P]),
     "wrk_runtime_state": (_P, [_P]),
+    "wrk_runtime_model_v6": (_P, [_P]),
     "wrk_runtime_infer": (C.c_int32, [_P, _P, _f32p, C.c_size_t, _u32p, C.c_uint32]),
 }
 for _lib, _tab in ((hip, HIP_SYMBOLS), (rt, RT_SYMBOLS)):
@@ -321,9 +331,24 @@ class TensorOp:
         d = x.desc(); x.ctx.check(hip.wrk_op_l2_norm(x.ctx.h, C.byref(d), eps))
 
     @staticmethod
-    def token_shift(cursors: Buffer, time_mix: Buffer, state: Tensor, inp: Tensor, out: Tensor, reversed_: bool):
-        s, i, o = state.desc(), inp.desc(), out.desc()
-        inp.ctx.check(hip.wrk_op_token_shift(inp.ctx.h, cursors.h, time_mix.h, C.byref(s), C.byref(i), C.byref(o), int(reversed_)))
+    def token_shift(cursors: Buffer, time_mix: Tensor, state: Tensor, inp: Tensor, out: Tensor, reversed_: bool):
+        m, s, i, o = time_mix.desc(), state.desc(), inp.desc(), out.desc()
+        inp.ctx.check(hip.wrk_op_token_shift(inp.ctx.h, cursors.h, C.byref(m), C.byref(s), C.byref(i), C.byref(o), int(reversed_)))
+
+    @staticmethod
+    def transpose(inp: Tensor, out: Tensor):
+        i, o = inp.desc(), out.desc()
+        out.ctx.check(hip.wrk_op_transpose(out.ctx.h, C.byref(i), C.byref(o)))
+
+    @staticmethod
+    def time_mix_v6(cursors: Buffer, time_decay: Tensor, time_first: Buffer, state: Tensor, k: Tensor, v: Tensor, r: Tensor, x: Tensor):
+        dd, ds, dk, dv, dr, dx = time_decay.desc(), state.desc(), k.desc(), v.desc(), r.desc(), x.desc()
+        x.ctx.check(hip.wrk_op_time_mix_v6(x.ctx.h, cursors.h, C.byref(dd), time_first.h, C.byref(ds), C.byref(dk), C.byref(dv), C.byref(dr), C.byref(dx)))
+
+    @staticmethod
+    def channel_mix(cursors: Buffer, state: Tensor, r: Tensor, v: Tensor, x: Tensor):
+        ds, dr, dv, dx = state.desc(), r.desc(), v.desc(), x.desc()
+        x.ctx.check(hip.wrk_op_channel_mix(x.ctx.h, cursors.h, C.byref(ds), C.byref(dr), C.byref(dv), C.byref(dx)))
 
     @staticmethod
     def add_activate(inp: Tensor, out: Tensor, act_x="none", act_y="none", act_out="none"):
@@ -517,9 +542,12 @@ class Runtime:
         self.info = ModelInfo()
         rt.wrk_runtime_info(h, C.byref(self.info))
         self.model = rt.wrk_runtime_model(h)
+        self.model6 = rt.wrk_runtime_model_v6(h)
         self.state = rt.wrk_runtime_state(h)
 
     def token_bytes(self, num_batch: int = 1) -> int:
+        if self.model6:
+            return hip.wrk_v6_model_token_bytes(self.model6, num_batch)
         return hip.wrk_v7_model_token_bytes(self.model, num_batch)
 
     def infer(self, inp: RnnInput, mode: int = 1) -> List[np.ndarray]:
@@ -541,8 +569,9 @@ class Runtime:
         V = self.info.num_vocab
         logits = np.empty((max(h.size, 1), V), np.float32)
         am = np.zeros(max(h.size, 1), np.uint32)
-        self.ctx.check(hip.wrk_v7_infer(self.ctx.h, self.model, self.state, _ptr(t, _u32p), None, _ptr(c, _u32p), t.size,
-                                        _ptr(h, _u32p), h.size, _ptr(logits, _f32p), _ptr(am, _u32p) if want_argmax else None, mode))
+        fn, mdl = (hip.wrk_v6_infer, self.model6) if self.model6 else (hip.wrk_v7_infer, self.model)
+        self.ctx.check(fn(self.ctx.h, mdl, self.state, _ptr(t, _u32p), None, _ptr(c, _u32p), t.size,
+                          _ptr(h, _u32p), h.size, _ptr(logits, _f32p), _ptr(am, _u32p) if want_argmax else None, mode))
         return (logits[: h.size], am[: h.size]) if want_argmax else logits[: h.size]
 
     def generate_greedy(self, first_tokens, steps: int, mode: int = 1, want_logits: bool = False):
@@ -552,8 +581,9 @@ class Runtime:
         out = np.zeros((steps, B), np.uint32)
         ms = C.c_float()
         logits = np.empty((B, self.info.num_vocab), np.float32) if want_logits else None
-        self.ctx.check(hip.wrk_v7_generate_greedy(self.ctx.h, self.model, self.state, _ptr(ft, _u32p), B, steps, _ptr(out, _u32p),
-                                                  _ptr(logits, _f32p) if want_logits else None, C.byref(ms), mode))
+        fn, mdl = (hip.wrk_v6_generate_greedy, self.model6) if self.model6 else (hip.wrk_v7_generate_greedy, self.model)
+        self.ctx.check(fn(self.ctx.h, mdl, self.state, _ptr(ft, _u32p), B, steps, _ptr(out, _u32p),
+                          _ptr(logits, _f32p) if want_logits else None, C.byref(ms), mode))
         return (out, ms.value, logits) if want_logits else (out, ms.value)
 
     def state_back(self, batch: int) -> np.ndarray:
