@@ -139,10 +139,20 @@ int32_t wrk_program_destroy(wrk_program* prog);
  * no bytes are added to the weight stream beyond 16-byte row alignment. */
 int32_t wrk_matrix_create(wrk_ctx* ctx, uint32_t kind, uint32_t k, uint32_t m,
                           const void* data, size_t bytes, uint32_t flags, wrk_matrix** out);
-/* Matrix::quant_u8 / quant_nf4 (matrix.rs:211-271; quant_mat_int8.wgsl, quant_mat_nf4.wgsl):
- * on-device quantisation of an f16 [K, M] tensor */
+/* web-rwkv's own formats through wrk_matrix_create (Matrix::Int8 { w, m } / Matrix::Fp4 { w, q, m },
+ * matrix.rs:79-130; the direct-load arms loader.rs:808-820, 901-918):
+ *   WRK_MAT_INT8: data = u8 codes [K*M] ++ (min, max) f16 pairs, one per 128 flattened elements; K % 128 == 0
+ *   WRK_MAT_NF4 : data = nibbles [K*M/2] (element 2i in the low nibble) ++ absmax f16, one per 64 flattened
+ *                 elements, optionally ++ the 16 f32 levels of `q` (default: the NF4 levels matrix.rs:50-67;
+ *                 pass Float4Quant::new_student's for SF4); K % 64 == 0
+ *
+ * Matrix::quant_u8 / quant_nf4 / quant_sf4 (matrix.rs:211-271; quant_mat_int8.wgsl, quant_mat_nf4.wgsl):
+ * on-device quantisation of an f16 [K, M] tensor (`f16_data`: M rows of K values).  `levels`: NULL for the
+ * NF4 levels, else 16 f32 (SF4); ignored for WRK_MAT_INT8. */
 int32_t wrk_matrix_quantize(wrk_ctx* ctx, uint32_t kind, uint32_t k, uint32_t m,
-                            const wrk_buf* f16_data, wrk_matrix** out);
+                            const wrk_buf* f16_data, const float* levels, wrk_matrix** out);
+/* read the quantised planes back in wrk_matrix_create's layout (tests; Matrix serialisation): INT8 / NF4 only */
+int32_t wrk_matrix_export(wrk_matrix* mat, void* dst, size_t capacity, size_t* bytes);
 int32_t wrk_matrix_release(wrk_matrix* mat);
 /* stored bytes read per full pass over the matrix (the roofline's algorithmic bytes) */
 size_t wrk_matrix_stream_bytes(const wrk_matrix* mat);

@@ -87,9 +87,19 @@ enum {
     WRK_WEIGHTS_REFERENCE = 2     /* the reference at HEAD literally: CPU dequant to f16, F16 matrices     */
 };
 
+enum { WRK_QUANT_NONE = 0, WRK_QUANT_INT8 = 1, WRK_QUANT_NF4 = 2 };   /* Quant (runtime/model.rs); SF4 needs the caller's
+                                                                          Student-t levels: wrk_matrix_quantize only */
+
 typedef struct wrk_build_options {
     uint32_t rescale;             /* ModelBuilder::rescale, 0 = default 1024 (v7.rs:50)  */
     uint32_t weights;             /* WRK_WEIGHTS_* */
+    /* ModelBuilder::quant (HashMap<usize, Quant>): quant[l] = WRK_QUANT_* for layer l < num_quant, NONE beyond.
+     * Applies to att.{key,value,receptance,gate,output} and ffn.{key,value,receptance} (v7.rs:1168-1186,
+     * v6.rs:1110-1132) exactly as Loader::load_matrix / load_matrix_discount do (loader.rs:756-951):
+     * Q8_0 + Int8 and Q4_0 + NF4 tensors loaded without discount are repacked on the host (gguf.rs:429-627),
+     * everything else goes f16 -> (discount) -> on-device quantisation. */
+    const uint8_t* quant;
+    uint32_t num_quant;
 } wrk_build_options;
 
 /* ModelBuilder::new(&context, reader).build_v7() + v7::Bundle::new(model, num_batch) + SimpleRuntime::new */

@@ -53,7 +53,9 @@ class V6Model:
     rescale: int = 6
 
 
-def build_v6(reader: GgufReader, weights_f16: bool = True, rescale: int = 6) -> V6Model:
+def build_v6(reader: GgufReader, weights_f16: bool = True, rescale: int = 6, quant=None) -> V6Model:
+    """quant: layer -> "int8" | "nf4" (ModelBuilder::quant, v6.rs:1045)."""
+    quant = quant or {}
     info = loader_info_v6(reader)
     D, R = info.num_emb, info.custom["time_mix"]
     layers = []
@@ -72,12 +74,13 @@ def build_v6(reader: GgufReader, weights_f16: bool = True, rescale: int = 6) -> 
         shp = reader.shape(f"{att}.time_mix_w2")                                                     # [5, D, R]
         p["time_mix_w2"] = r16(reader.tensor(f"{att}.time_mix_w2")[2]).reshape(shp)
         p["gn_w"], p["gn_b"] = _vec16(reader, f"{att}.ln_x.weight"), _vec16(reader, f"{att}.ln_x.bias")
+        q = quant.get(l, "none")
         for n, k in (("w_k", "key"), ("w_v", "value"), ("w_r", "receptance"), ("w_g", "gate"), ("w_o", "output")):
-            p[n] = _mat(reader, f"{att}.{k}.weight", weights_f16)
+            p[n] = _mat(reader, f"{att}.{k}.weight", weights_f16, q, discount if n == "w_o" else np.float32(1.0))
         p["ffn_mix_k"], p["ffn_mix_r"] = _vec16(reader, f"{ffn}.time_mix_k"), _vec16(reader, f"{ffn}.time_mix_r")
         for n, k in (("ffn_w_k", "key"), ("ffn_w_v", "value"), ("ffn_w_r", "receptance")):
-            p[n] = _mat(reader, f"{ffn}.{k}.weight", weights_f16)
-        if discount != 1.0:
+            p[n] = _mat(reader, f"{ffn}.{k}.weight", weights_f16, q, discount if n == "ffn_w_v" else np.float32(1.0))
+        if discount != 1.0 and q == "none":
             for n in ("w_o", "ffn_w_v"):
                 p[n] = r16(discount * p[n]) if weights_f16 else (discount * p[n]).astype(np.float32)
         layers.append(p)

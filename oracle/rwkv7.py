@@ -144,10 +144,28 @@ def _mat16(reader, name):
     return r16(v).reshape(shape[0], shape[1])
 
 
-def _mat(reader: GgufReader, name: str, weights_f16: bool) -> np.ndarray:
-    """load_matrix (loader.rs:756-789).  weights_f16=True is the reference at HEAD (F1);
-    False lifts the gate and keeps ggml-canonical f32 dequantised values (north_star path)."""
+def _mat(reader: GgufReader, name: str, weights_f16: bool, quant: str = "none", discount=np.float32(1.0)) -> np.ndarray:
+    """load_matrix / load_matrix_discount (loader.rs:756-789, 923-951).  weights_f16=True is the reference at
+    HEAD (F1); False lifts the gate and keeps ggml-canonical f32 dequantised values (north_star path).
+    quant "int8" / "nf4" (ModelBuilder::quant): the live direct arms for Q8_0 / Q4_0 sources loaded without a
+    discount (loader.rs:808-820, 901-918), otherwise f16 -> discount -> Matrix::quant_u8 / quant_nf4; the
+    returned array holds the values the matmul shaders reconstruct (matmul_vec_int8/nf4.wgsl)."""
     shape = reader.shape(name)
+    if quant != "none":
+        from . import wrkquant as wq
+        n = shape[0] * shape[1]
+        qt = reader.quantized_tensor(name) if discount == 1.0 else None
+        if qt is not None and qt[0] == dq.GGML_TYPE_ID["Q8_0"] and quant == "int8":
+            return wq.dequantize_int8(*wq.repack_q8_0_to_int8(np.frombuffer(qt[1], np.uint8), n)).reshape(shape[0], shape[1])
+        if qt is not None and qt[0] == dq.GGML_TYPE_ID["Q4_0"] and quant == "nf4":
+            return wq.dequantize_nf4(*wq.repack_q4_0_to_nf4(np.frombuffer(qt[1], np.uint8), n)).reshape(shape[0], shape[1])
+        w = _mat16(reader, name)
+        if discount != 1.0:
+            w = r16(discount * w)
+        w16 = w.astype(np.float16)
+        if quant == "int8":
+            return wq.dequantize_int8(*wq.quantize_int8(w16)).reshape(shape[0], shape[1])
+        return wq.dequantize_nf4(*wq.quantize_nf4(w16)).reshape(shape[0], shape[1])
     if weights_f16:
         return _mat16(reader, name)
     tn, raw = reader.raw_tensor(name)
@@ -170,9 +188,10 @@ class V7Model:
     rescale: int = 1024
 
 
-def build_v7(reader: GgufReader, weights_f16: bool = True, rescale: int = 1024) -> V7Model:
-    """ModelBuilder::build_v7 (v7.rs:1038-1227).  LoRA blending and on-load Int8/NF4 are not
-    restated here (GGUF path ignores LoRA; Quant::None)."""
+def build_v7(reader: GgufReader, weights_f16: bool = True, rescale: int = 1024, quant: Optional[Dict[int, str]] = None) -> V7Model:
+    """ModelBuilder::build_v7 (v7.rs:1038-1227).  LoRA blending is not restated (the GGUF path ignores LoRA).
+    quant: layer -> "int8" | "nf4" (ModelBuilder::quant, v7.rs:1089)."""
+    quant = quant or {}
     info = loader_info(reader)
     emb = _mat16(reader, "emb.weight")                                   # CPU f16, v7.rs:1065
     ln0 = (_vec16(reader, "blocks.0.ln0.weight"), _vec16(reader, "blocks.0.ln0.bias"))
@@ -197,14 +216,15 @@ def build_v7(reader: GgufReader, weights_f16: bool = True, rescale: int = 1024) 
             p["v1"], p["v2"] = _mat16(reader, f"{att}.v1"), _mat16(reader, f"{att}.v2")
         p["r_k"] = _mat16(reader, f"{att}.r_k").reshape(-1)              # [H, S] flattened
         p["gn_w"], p["gn_b"] = _vec16(reader, f"{att}.ln_x.weight"), _vec16(reader, f"{att}.ln_x.bias")
-        p["w_k"] = _mat(reader, f"{att}.key.weight", weights_f16)
-        p["w_v"] = _mat(reader, f"{att}.value.weight", weights_f16)
-        p["w_r"] = _mat(reader, f"{att}.receptance.weight", weights_f16)
-        p["w_o"] = _mat(reader, f"{att}.output.weight", weights_f16)
+        q = quant.get(layer, "none")
+        p["w_k"] = _mat(reader, f"{att}.key.weight", weights_f16, q)
+        p["w_v"] = _mat(reader, f"{att}.value.weight", weights_f16, q)
+        p["w_r"] = _mat(reader, f"{att}.receptance.weight", weights_f16, q)
+        p["w_o"] = _mat(reader, f"{att}.output.weight", weights_f16, q, discount)
         p["ffn_x_k"] = _vec16(reader, f"{ffn}.x_k")
-        p["ffn_w_k"] = _mat(reader, f"{ffn}.key.weight", weights_f16)
-        p["ffn_w_v"] = _mat(reader, f"{ffn}.value.weight", weights_f16)
-        if discount != 1.0:                                              # load_matrix_f16_discount, loader.rs:643-652
+        p["ffn_w_k"] = _mat(reader, f"{ffn}.key.weight", weights_f16, q)
+        p["ffn_w_v"] = _mat(reader, f"{ffn}.value.weight", weights_f16, q, discount)
+        if discount != 1.0 and q == "none":                                              # load_matrix_f16_discount, loader.rs:643-652
             p["w_o"] = r16(discount * p["w_o"]) if weights_f16 else (discount * p["w_o"]).astype(np.float32)
             p["ffn_w_v"] = r16(discount * p["ffn_w_v"]) if weights_f16 else (discount * p["ffn_w_v"]).astype(np.float32)
         layers.append(V7Layer(p))

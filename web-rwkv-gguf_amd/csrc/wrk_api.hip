@@ -205,6 +205,23 @@ static inline uint16_t f32_to_f16_bits(float f) {
     return b;
 }
 
+// Float4Quant::default (matrix.rs:50-67)
+static const float NF4_LEVELS[16] = {-1.0f, -0.6961928009986877f, -0.5250730514526367f, -0.39491748809814453f,
+                                     -0.28444138169288635f, -0.18477343022823334f, -0.09105003625154495f, 0.0f,
+                                     0.07958029955625534f, 0.16093020141124725f, 0.24611230194568634f, 0.33791524171829224f,
+                                     0.44070982933044434f, 0.5626170039176941f, 0.7229568362236023f, 1.0f};
+
+static int32_t upload_levels(wrk_ctx* ctx, wrk_matrix* mt, const float* levels) {
+    void* q = nullptr;
+    WRK_HIP(ctx, hipMalloc(&q, 64));
+    hipError_t e = hipMemcpyAsync(q, levels ? levels : NF4_LEVELS, 64, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { hipFree(q); return wrk_fail(ctx, WRK_E_HIP, "fp4 level upload: %s", hipGetErrorString(e)); }
+    mt->aux = (uint8_t*)q;
+    mt->aux_bytes = 64;
+    return WRK_OK;
+}
+
 int32_t wrk_matrix_create(wrk_ctx* ctx, uint32_t kind, uint32_t k, uint32_t m, const void* data, size_t bytes, uint32_t flags,
                           wrk_matrix** out) {
     if (!ctx || !out || !data) return WRK_E_ARG;
@@ -213,6 +230,7 @@ int32_t wrk_matrix_create(wrk_ctx* ctx, uint32_t kind, uint32_t k, uint32_t m, c
     WRK_ARG(ctx, k > 0 && m > 0, "matrix dims must be positive");
     uint32_t dev_kind = kind;
     size_t expect = 0;
+    const float* levels = nullptr;
     switch (kind) {
         case WRK_MAT_F32: expect = (size_t)k * m * 4; dev_kind = WRK_MAT_F16; break;
         case WRK_MAT_F16: expect = (size_t)k * m * 2; break;
@@ -225,6 +243,15 @@ int32_t wrk_matrix_create(wrk_ctx* ctx, uint32_t kind, uint32_t k, uint32_t m, c
         case WRK_MAT_Q6_K:
             WRK_ARG(ctx, k % 256 == 0, "K-quants need K %% 256 == 0 (loader.rs:824-827)");
             expect = wrk::stored_bytes(kind, k, m);
+            break;
+        case WRK_MAT_INT8:
+            WRK_ARG(ctx, k % 128 == 0, "Int8 matrices need K %% 128 == 0 (INT8_BLOCK_SIZE, ops.rs)");
+            expect = wrk::stored_bytes(kind, k, m);
+            break;
+        case WRK_MAT_NF4:
+            WRK_ARG(ctx, k % 64 == 0, "NF4 matrices need K %% 64 == 0 (NF4_BLOCK_SIZE, ops.rs)");
+            expect = wrk::stored_bytes(kind, k, m);
+            if (bytes == expect + 64) { levels = (const float*)((const uint8_t*)data + expect); bytes = expect; }
             break;
         default: return wrk_fail(ctx, WRK_E_UNSUPPORTED, "matrix kind %u not supported by wrk_matrix_create", kind);
     }
@@ -248,13 +275,67 @@ int32_t wrk_matrix_create(wrk_ctx* ctx, uint32_t kind, uint32_t k, uint32_t m, c
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { hipFree(p); return wrk_fail(ctx, WRK_E_HIP, "matrix upload: %s", hipGetErrorString(e)); }
     wrk_matrix* mt = new wrk_matrix{ctx, dev_kind, k, m, flags, (uint8_t*)p, rb, wrk::stored_bytes(kind, k, m), nullptr, 0, {1}};
+    if (kind == WRK_MAT_NF4) {
+        const int32_t rc = upload_levels(ctx, mt, levels);
+        if (rc != WRK_OK) { hipFree(p); delete mt; return rc; }
+    }
     *out = mt;
     return WRK_OK;
 }
 
-int32_t wrk_matrix_quantize(wrk_ctx* ctx, uint32_t kind, uint32_t, uint32_t, const wrk_buf*, wrk_matrix** out) {
-    if (out) *out = nullptr;
-    return wrk_fail(ctx, WRK_E_UNSUPPORTED, "on-load Int8/NF4 quantisation (kind %u) is not built yet", kind);
+int32_t wrk_matrix_quantize(wrk_ctx* ctx, uint32_t kind, uint32_t k, uint32_t m, const wrk_buf* f16_data, const float* levels,
+                            wrk_matrix** out) {
+    if (!ctx || !out || !f16_data) return WRK_E_ARG;
+    LOCK(ctx);
+    *out = nullptr;
+    WRK_ARG(ctx, k > 0 && m > 0, "matrix dims must be positive");
+    if (kind != WRK_MAT_INT8 && kind != WRK_MAT_NF4)
+        return wrk_fail(ctx, WRK_E_UNSUPPORTED, "wrk_matrix_quantize: kind %u is not Int8 / NF4", kind);
+    WRK_ARG(ctx, kind != WRK_MAT_INT8 || k % 128 == 0, "Int8 matrices need K %% 128 == 0");
+    WRK_ARG(ctx, kind != WRK_MAT_NF4 || k % 64 == 0, "NF4 matrices need K %% 64 == 0");
+    WRK_ARG(ctx, f16_data->bytes >= (size_t)k * m * 2, "source holds %zu bytes, [%u x %u] f16 needs %zu", f16_data->bytes, k, m, (size_t)k * m * 2);
+    WRK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t rb = wrk::repack_row_bytes(kind, k);
+    void* p = nullptr;
+    WRK_HIP(ctx, hipMalloc(&p, rb * m + 256));
+    wrk_matrix* mt = new wrk_matrix{ctx, kind, k, m, 0, (uint8_t*)p, rb, wrk::stored_bytes(kind, k, m), nullptr, 0, {1}};
+    hipError_t e = hipMemsetAsync(p, 0, rb * m + 256, ctx->stream);
+    if (e == hipSuccess && kind == WRK_MAT_INT8) wrk::quantize_int8(ctx->stream, f16_data->ptr, mt->data, k, m, (uint32_t)rb);
+    if (e == hipSuccess && kind == WRK_MAT_NF4) {
+        const int32_t rc = upload_levels(ctx, mt, levels);
+        if (rc != WRK_OK) { hipFree(p); delete mt; return rc; }
+        wrk::quantize_nf4(ctx->stream, f16_data->ptr, (const float*)mt->aux, mt->data, k, m, (uint32_t)rb);
+    }
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) { hipFree(p); if (mt->aux) hipFree(mt->aux); delete mt; return wrk_fail(ctx, WRK_E_HIP, "matrix quantize: %s", hipGetErrorString(e)); }
+    *out = mt;
+    return WRK_OK;
+}
+
+int32_t wrk_matrix_export(wrk_matrix* mat, void* dst, size_t capacity, size_t* bytes) {
+    if (!mat || !bytes) return WRK_E_ARG;
+    wrk_ctx* ctx = mat->ctx;
+    LOCK(ctx);
+    if (mat->kind != WRK_MAT_INT8 && mat->kind != WRK_MAT_NF4)
+        return wrk_fail(ctx, WRK_E_UNSUPPORTED, "wrk_matrix_export: only Int8 / NF4 matrices keep their source layout");
+    const uint32_t k = mat->k, m = mat->m;
+    const size_t total = wrk::stored_bytes(mat->kind, k, m) + (mat->kind == WRK_MAT_NF4 ? 64 : 0);
+    *bytes = total;
+    if (!dst) return WRK_OK;
+    WRK_ARG(ctx, capacity >= total, "export needs %zu bytes, capacity %zu", total, capacity);
+    WRK_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<uint8_t> host(mat->row_bytes * m);
+    WRK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    WRK_HIP(ctx, hipMemcpy(host.data(), mat->data, host.size(), hipMemcpyDeviceToHost));
+    uint8_t* o = (uint8_t*)dst;
+    const size_t code_row = mat->kind == WRK_MAT_INT8 ? k : k / 2;
+    const size_t side_row = mat->kind == WRK_MAT_INT8 ? (size_t)(k / 128) * 4 : (size_t)(k / 64) * 2;
+    for (uint32_t r = 0; r < m; ++r) {
+        memcpy(o + (size_t)r * code_row, host.data() + (size_t)r * mat->row_bytes, code_row);
+        memcpy(o + (size_t)m * code_row + (size_t)r * side_row, host.data() + (size_t)r * mat->row_bytes + code_row, side_row);
+    }
+    if (mat->kind == WRK_MAT_NF4) WRK_HIP(ctx, hipMemcpy(o + total - 64, mat->aux, 64, hipMemcpyDeviceToHost));
+    return WRK_OK;
 }
 
 int32_t wrk_matrix_release(wrk_matrix* mat) {

@@ -41,8 +41,7 @@ struct wrk_matrix {
     uint8_t* data;          // re-laid-out weight stream (device)
     size_t row_bytes;       // device bytes per row (16-byte aligned)
     size_t stored_bytes;    // algorithmic bytes = GGUF/f16 stored size of the tensor
-    // INT8 / NF4 side tables (web-rwkv formats)
-    uint8_t* aux = nullptr;     // int8: (min,max) f16 per 128 elements; nf4: absmax f16 per 64 elements
+    uint8_t* aux = nullptr;     // Matrix::Fp4 { q }: the 16 f32 levels (device); side tables live in the row planes
     size_t aux_bytes = 0;
     std::atomic<int> refs;
 };
@@ -176,6 +175,9 @@ int matvec(hipStream_t s, const MatJob* jobs, int njobs, int num_cu);
 // MFMA dequant-GEMM (wrk_gemm.hip); -2 = not applicable (caller uses the matvec kernels).  xsum_scratch: device
 // f32 buffer of at least tokens * K/32 elements (only the K4 kinds use it)
 int matmul_mfma(hipStream_t s, const MatJob& job, int num_cu, float* xsum_scratch, size_t xsum_cap);
+// wrk_quant.hip
+void quantize_int8(hipStream_t s, const void* src_f16, uint8_t* dst, uint32_t k, uint32_t m, uint32_t row_bytes);
+void quantize_nf4(hipStream_t s, const void* src_f16, const float* levels, uint8_t* dst, uint32_t k, uint32_t m, uint32_t row_bytes);
 size_t repack_row_bytes(uint32_t kind, uint32_t k);
 int repack_rows(uint32_t kind, uint32_t k, uint32_t m, const uint8_t* src, uint8_t* dst);   // host side
 size_t stored_bytes(uint32_t kind, uint32_t k, uint32_t m);

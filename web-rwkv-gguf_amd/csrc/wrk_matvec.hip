@@ -34,6 +34,8 @@ size_t repack_row_bytes(uint32_t kind, uint32_t k) {
         case WRK_MAT_Q4_K: return align16(nb * 148);   // quants 128 | d,dmin 4 | unpacked 6-bit scales/mins 16
         case WRK_MAT_Q5_K: return align16(nb * 180);   // quants 128 | high bits 32 | d,dmin 4 | scales/mins 16
         case WRK_MAT_Q6_K: return align16(nb * 208 + nb * 2);
+        case WRK_MAT_INT8: return (k % 128) ? 0 : align16((size_t)k + (size_t)(k / 128) * 4);   // codes | (min, max) f16 per 128
+        case WRK_MAT_NF4: return (k % 64) ? 0 : align16((size_t)k / 2 + (size_t)(k / 64) * 2);   // nibbles | absmax f16 per 64
         default: return 0;
     }
 }
@@ -115,11 +117,24 @@ int repack_rows(uint32_t kind, uint32_t k, uint32_t m, const uint8_t* src, uint8
                 }
                 break;
             }
+            // web-rwkv's formats: `src` = codes of the flattened matrix followed by the side table of the flattened
+            // matrix (Matrix::Int8 { w, m } / Matrix::Fp4 { w, q, m }); k % block == 0 makes the side table per-row
+            case WRK_MAT_INT8: {
+                memcpy(d, src + (size_t)r * k, k);
+                memcpy(d + k, src + (size_t)m * k + (size_t)r * (k / 128) * 4, (size_t)(k / 128) * 4);
+                break;
+            }
+            case WRK_MAT_NF4: {
+                memcpy(d, src + (size_t)r * (k / 2), k / 2);
+                memcpy(d + k / 2, src + (size_t)m * (k / 2) + (size_t)r * (k / 64) * 2, (size_t)(k / 64) * 2);
+                break;
+            }
             default: break;
         }
     }
     return 0;
 }
+
 
 // ------------------------------------------------------------------ device: code -> f16 helpers
 // An integer code c < 1024 placed in the low bits of an f16 lane IS the subnormal c * 2^-24 (subnormals are
@@ -200,6 +215,7 @@ constexpr int MAX_JOBS = 8;
 
 struct JobDev {
     const uint8_t* w;
+    const float* aux;                  // NF4/SF4: the 16 f32 levels of Matrix::Fp4 { q }
     uint32_t kind, flags, k, m, row_bytes, act;
     uint32_t rows_per_wg, wg_begin;    // first workgroup (in x) of this job
     uint32_t has_res;                  // fused residual: out = round_out(act(acc)) + res   (matmul + TensorOp::add)
@@ -236,6 +252,8 @@ struct Raw {
 
 template <int KIND>
 __device__ __forceinline__ uint32_t num_chunks(uint32_t k, uint32_t kpad) {
+    if (KIND == WRK_MAT_INT8) return k >> 4;
+    if (KIND == WRK_MAT_NF4) return k >> 5;
     return KIND == WRK_MAT_F16 ? (kpad >> 3) : (KIND == WRK_MAT_Q8_0 ? (k >> 4) : (k >> 8) * 8);
 }
 
@@ -259,6 +277,10 @@ __device__ __forceinline__ Raw load_raw(const uint8_t* __restrict__ row, uint32_
         r.b.x = (uint32_t)scp[0] | ((uint32_t)scp[4] << 8) | (dbits << 16);
     } else if (KIND == WRK_MAT_Q8_0) {
         r.a.x = *(const uint16_t*)(row + (size_t)k + (size_t)(c >> 1) * 2);
+    } else if (KIND == WRK_MAT_INT8) {
+        r.a.x = *(const uint32_t*)(row + (size_t)k + (size_t)(c >> 3) * 4);          // (min, max) f16 of the 128-block
+    } else if (KIND == WRK_MAT_NF4) {
+        r.a.x = *(const uint16_t*)(row + (size_t)(k >> 1) + (size_t)(c >> 1) * 2);   // absmax f16 of the 64-block
     }
     return r;
 }
@@ -274,6 +296,16 @@ __device__ __forceinline__ void decode_raw(const Raw& r, uint32_t c, Group& lo, 
         bytes_to_h2(w.z ^ 0x80808080u, lo.q[4], lo.q[5]);
         bytes_to_h2(w.w ^ 0x80808080u, lo.q[6], lo.q[7]);
         lo.scale = f16bits_to_f32(r.a.x); lo.minv = 0.0f; lo.off = 128.0f; lo.qmul = Q24; lo.xoff = c * 16;
+        return;
+    }
+    if (KIND == WRK_MAT_INT8) {
+        // matmul_vec_int8.wgsl:89-92: w = fma(code / 255, max - min, min)
+        bytes_to_h2(w.x, lo.q[0], lo.q[1]);
+        bytes_to_h2(w.y, lo.q[2], lo.q[3]);
+        bytes_to_h2(w.z, lo.q[4], lo.q[5]);
+        bytes_to_h2(w.w, lo.q[6], lo.q[7]);
+        const float mn = f16bits_to_f32(r.a.x & 0xffffu), mx = f16bits_to_f32(r.a.x >> 16);
+        lo.scale = mx - mn; lo.minv = -mn; lo.off = 0.0f; lo.qmul = Q24 / 255.0f; lo.xoff = c * 16;
         return;
     }
     const uint32_t b = c >> 3, sub = c & 7u;
@@ -339,7 +371,8 @@ __device__ __forceinline__ void decode_raw(const Raw& r, uint32_t c, Group& lo, 
 template <int KIND>
 __device__ __forceinline__ void chunk_xoff(uint32_t c, uint32_t& lo, uint32_t& hi) {
     if (KIND == WRK_MAT_F16) { lo = c * 8; hi = lo; return; }
-    if (KIND == WRK_MAT_Q8_0) { lo = c * 16; hi = lo; return; }
+    if (KIND == WRK_MAT_Q8_0 || KIND == WRK_MAT_INT8) { lo = c * 16; hi = lo; return; }
+    if (KIND == WRK_MAT_NF4) { lo = c * 32; hi = lo + 16; return; }
     const uint32_t b = c >> 3, sub = c & 7u;
     if (KIND == WRK_MAT_Q6_K) { lo = b * 256 + (sub >> 2) * 128 + ((sub >> 1) & 1u) * 32 + (sub & 1u) * 16; hi = lo + 64; return; }
     lo = b * 256 + (sub >> 1) * 64 + (sub & 1u) * 16;
@@ -347,7 +380,8 @@ __device__ __forceinline__ void chunk_xoff(uint32_t c, uint32_t& lo, uint32_t& h
 }
 
 template <int KIND, bool R16, int NB>
-__device__ __forceinline__ void dot_raw(const Raw& r, uint32_t c, const f16* xs, const float* xsum, uint32_t kpad, float (&acc)[NB]) {
+__device__ __forceinline__ void dot_raw(const Raw& r, uint32_t c, const f16* xs, const float* xsum, uint32_t kpad, float (&acc)[NB],
+                                        const float* __restrict__ levels = nullptr) {
     if (KIND == WRK_MAT_F16) {
         const f16x8 wv = __builtin_bit_cast(f16x8, r.w);
 #pragma unroll
@@ -362,9 +396,32 @@ __device__ __forceinline__ void dot_raw(const Raw& r, uint32_t c, const f16* xs,
         }
         return;
     }
+    if (KIND == WRK_MAT_NF4) {
+        // matmul_vec_nf4.wgsl:47-80: w = level[q] * absmax, f32; nibble i of a dword is element i
+        const float amax = f16bits_to_f32(r.a.x);
+        const uint32_t wd[4] = {r.w.x, r.w.y, r.w.z, r.w.w};
+#pragma unroll
+        for (int wi = 0; wi < 4; ++wi) {
+            float wv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                wv[i] = levels[(wd[wi] >> (4 * i)) & 15u] * amax;
+                if (R16) wv[i] = (float)(f16)wv[i];
+            }
+#pragma unroll
+            for (int n = 0; n < NB; ++n) {
+                const f16x8 x = *(const f16x8*)(xs + (size_t)n * kpad + c * 32 + wi * 8);
+                float a = acc[n];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) a = fmaf(wv[i], (float)x[i], a);
+                acc[n] = a;
+            }
+        }
+        return;
+    }
     Group lo, hi;
     decode_raw<KIND>(r, c, lo, hi);
-    groups_accumulate<R16, NB>(lo, hi, KIND != WRK_MAT_Q8_0, xs, xsum, kpad, acc);
+    groups_accumulate<R16, NB>(lo, hi, KIND != WRK_MAT_Q8_0 && KIND != WRK_MAT_INT8, xs, xsum, kpad, acc);
 }
 
 // ------------------------------------------------------------------ register-resident inputs (single input vector)
@@ -569,7 +626,7 @@ __device__ __forceinline__ void matvec_body(const JobDev& J, unsigned char* smem
             if (c < nch) {
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb)
-                    if (ri0 + rb < nrows) dot_raw<KIND, R16, NB>(raw[rb], c, xs, xsum, kpad, acc[rb]);
+                    if (ri0 + rb < nrows) dot_raw<KIND, R16, NB>(raw[rb], c, xs, xsum, kpad, acc[rb], J.aux);
             }
         }
 #pragma unroll
@@ -752,6 +809,8 @@ __global__ void __launch_bounds__(256) matvec_kernel(const MatvecParams P) {
         case WRK_MAT_Q5_K: if (r16w) matvec_body<WRK_MAT_Q5_K, true, NB>(J, smem); else matvec_body<WRK_MAT_Q5_K, false, NB>(J, smem); break;
         case WRK_MAT_Q6_K: if (r16w) matvec_body<WRK_MAT_Q6_K, true, NB>(J, smem); else matvec_body<WRK_MAT_Q6_K, false, NB>(J, smem); break;
         case WRK_MAT_Q8_0: if (r16w) matvec_body<WRK_MAT_Q8_0, true, NB>(J, smem); else matvec_body<WRK_MAT_Q8_0, false, NB>(J, smem); break;
+        case WRK_MAT_INT8: matvec_body<WRK_MAT_INT8, false, NB>(J, smem); break;
+        case WRK_MAT_NF4: matvec_body<WRK_MAT_NF4, false, NB>(J, smem); break;
         default: matvec_body<WRK_MAT_F16, false, NB>(J, smem); break;
     }
 }
@@ -886,7 +945,7 @@ int matvec(hipStream_t s, const MatJob* jobs, int njobs, int num_cu) {
     uint32_t wg = 0;
     for (int j = 0; j < njobs; ++j) {
         JobDev& d = P.jobs[j];
-        d.w = jobs[j].w; d.kind = jobs[j].kind; d.flags = jobs[j].flags; d.k = jobs[j].k; d.m = jobs[j].m;
+        d.w = jobs[j].w; d.aux = (const float*)jobs[j].aux; d.kind = jobs[j].kind; d.flags = jobs[j].flags; d.k = jobs[j].k; d.m = jobs[j].m;
         d.row_bytes = jobs[j].row_bytes; d.act = jobs[j].act; d.rows_per_wg = rpw; d.wg_begin = wg;
         d.in = jobs[j].in; d.out = jobs[j].out; d.res = jobs[j].res; d.has_res = jobs[j].has_res;
         d.amax_val = jobs[j].amax_val; d.amax_idx = jobs[j].amax_idx;

@@ -9,6 +9,8 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cfloat>
+#include <cmath>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -85,6 +87,76 @@ void dequant_q4_0(const uint8_t* d, size_t n, uint16_t* out) {                  
             out[b * 32 + 2 * i] = f2h((float)lo * scale);
             out[b * 32 + 2 * i + 1] = f2h((float)hi * scale);
         }
+    }
+}
+
+// repack_q8_0_to_int8 (gguf.rs:429-520): four Q8_0 blocks -> one 128-element Int8 block.  Output in
+// wrk_matrix_create's WRK_MAT_INT8 layout: codes [n] ++ (min, max) f16 per block.  n % 128 == 0 here.
+void repack_q8_0_to_int8(const uint8_t* d, size_t n, std::vector<uint8_t>& blob) {
+    const long long nblk = (long long)(n / 128);
+    blob.assign(n + (size_t)nblk * 4, 0);
+    uint8_t* codes = blob.data();
+    uint16_t* minmax = (uint16_t*)(blob.data() + n);
+#pragma omp parallel for schedule(static)
+    for (long long b = 0; b < nblk; ++b) {
+        float val[128];
+        float mn = FLT_MAX, mx = -FLT_MAX;
+        for (int i = 0; i < 4; ++i) {
+            const uint8_t* blk = d + (b * 4 + i) * 34;
+            const float scale = ld_f16(blk);
+            for (int j = 0; j < 32; ++j) {
+                const float v = (float)(int8_t)blk[2 + j] * scale;
+                val[i * 32 + j] = v;
+                mn = std::min(mn, v);
+                mx = std::max(mx, v);
+            }
+        }
+        minmax[2 * b] = f2h(mn);
+        minmax[2 * b + 1] = f2h(mx);
+        const float range = mx - mn, inv = range > 0.0f ? 255.0f / range : 0.0f;
+        for (int e = 0; e < 128; ++e) {
+            const float t = roundf((val[e] - mn) * inv);                 // f32::round: half away from zero
+            codes[b * 128 + e] = (uint8_t)std::min(std::max(t, 0.0f), 255.0f);   // `as u8` saturates
+        }
+    }
+}
+
+// repack_q4_0_to_nf4 (gguf.rs:528-627): two Q4_0 blocks -> one 64-element NF4 block; nibbles [n/2] ++ absmax f16
+void repack_q4_0_to_nf4(const uint8_t* d, size_t n, std::vector<uint8_t>& blob) {
+    static const float LEVELS[16] = {-1.0f, -0.6961928009986877f, -0.5250730514526367f, -0.39491748809814453f,
+                                     -0.28444138169288635f, -0.18477343022823334f, -0.09105003625154495f, 0.0f,
+                                     0.07958029955625534f, 0.16093020141124725f, 0.24611230194568634f, 0.33791524171829224f,
+                                     0.44070982933044434f, 0.5626170039176941f, 0.7229568362236023f, 1.0f};
+    const long long nblk = (long long)(n / 64);
+    blob.assign(n / 2 + (size_t)nblk * 2, 0);
+    uint8_t* packed = blob.data();
+    uint16_t* absmax = (uint16_t*)(blob.data() + n / 2);
+#pragma omp parallel for schedule(static)
+    for (long long b = 0; b < nblk; ++b) {
+        float val[64];
+        float amax = 0.0f;
+        for (int i = 0; i < 2; ++i) {
+            const uint8_t* blk = d + (b * 2 + i) * 18;
+            const float scale = ld_f16(blk);
+            for (int j = 0; j < 16; ++j) {
+                const float lo = (float)((int)(blk[2 + j] & 0x0F) - 8) * scale, hi = (float)((int)(blk[2 + j] >> 4) - 8) * scale;
+                val[i * 32 + 2 * j] = lo;
+                val[i * 32 + 2 * j + 1] = hi;
+                amax = std::max(std::max(amax, std::fabs(lo)), std::fabs(hi));
+            }
+        }
+        absmax[b] = f2h(amax);
+        const float inv = amax > 0.0f ? 1.0f / amax : 0.0f;
+        auto nearest = [&](float x) {       // Iterator::min_by keeps the FIRST minimum
+            int best = 0;
+            float err = std::fabs(LEVELS[0] - x);
+            for (int q = 1; q < 16; ++q) {
+                const float e = std::fabs(LEVELS[q] - x);
+                if (e < err) { err = e; best = q; }
+            }
+            return (uint8_t)best;
+        };
+        for (int e = 0; e < 32; ++e) packed[b * 32 + e] = nearest(val[2 * e] * inv) | (nearest(val[2 * e + 1] * inv) << 4);
     }
 }
 
@@ -755,6 +827,7 @@ int32_t wrk_runtime_create(wrk_ctx* ctx, const wrk_gguf* g, const wrk_build_opti
         return WRK_OK;
     };
     // load_matrix / load_matrix_f16 / load_matrix_discount (loader.rs:617-670, 756-951)
+    uint32_t layer_quant = WRK_QUANT_NONE;     // Quant of the layer being built (ModelBuilder::quant)
     auto mat = [&](const std::string& name, uint32_t k, uint32_t m, bool big, float discount, wrk_matrix** o) -> int32_t {
         std::vector<size_t> shp;
         if (!g->shape(name, shp) || shp.size() != 2) return fail(WRK_E_ARG, "tensor not found: %s", name.c_str());
@@ -762,6 +835,38 @@ int32_t wrk_runtime_create(wrk_ctx* ctx, const wrk_gguf* g, const wrk_build_opti
         const TensorInfo* ti = g->info(name);
         wrk_matrix* mt = nullptr;
         int32_t r;
+        const uint32_t quant = big ? layer_quant : (uint32_t)WRK_QUANT_NONE;
+        if (quant != WRK_QUANT_NONE) {
+            const size_t n = (size_t)k * m;
+            const uint32_t kind = quant == WRK_QUANT_INT8 ? WRK_MAT_INT8 : WRK_MAT_NF4;
+            // try_load_matrix_direct's live arms (loader.rs:808-820, 901-918); load_matrix_discount never takes them
+            if (discount == 1.0f && quant == WRK_QUANT_INT8 && ti->type == T_Q8_0 && k % 128 == 0) {
+                std::vector<uint8_t> blob;
+                repack_q8_0_to_int8(g->tensor_data(*ti), n, blob);
+                r = wrk_matrix_create(ctx, kind, k, m, blob.data(), blob.size(), WRK_MATRIX_EXACT, &mt);
+            } else if (discount == 1.0f && quant == WRK_QUANT_NF4 && ti->type == T_Q4_0 && k % 64 == 0) {
+                std::vector<uint8_t> blob;
+                repack_q4_0_to_nf4(g->tensor_data(*ti), n, blob);
+                r = wrk_matrix_create(ctx, kind, k, m, blob.data(), blob.size(), WRK_MATRIX_EXACT, &mt);
+            } else {
+                // load_in_place_matrix_f16[_discount] + Matrix::quant_u8 / quant_nf4 (loader.rs:770-781, 932-943)
+                std::vector<uint16_t> v;
+                r = g->tensor_f16(name, v);
+                if (r != WRK_OK) return r;
+                if (discount != 1.0f)
+                    for (auto& h : v) h = f2h(discount * h2f(h));
+                wrk_buf* src = nullptr;
+                r = wrk_buf_create(ctx, v.size() * 2, v.data(), &src);
+                if (r != WRK_OK) return fail(r, "upload %s: %s", name.c_str(), wrk_last_error(ctx));
+                r = wrk_matrix_quantize(ctx, kind, k, m, src, nullptr, &mt);
+                wrk_ctx_sync(ctx);
+                wrk_buf_release(src);
+            }
+            if (r != WRK_OK) return fail(r, "quantise %s: %s", name.c_str(), wrk_last_error(ctx));
+            rt->mats.push_back(mt);
+            *o = mt;
+            return WRK_OK;
+        }
         const bool direct = big && weights != WRK_WEIGHTS_REFERENCE && discount == 1.0f &&
                             (ti->type == T_Q4K || ti->type == T_Q5K || ti->type == T_Q6K || ti->type == T_Q8_0) &&
                             (ti->type == T_Q8_0 ? k % 32 == 0 : k % 256 == 0);
@@ -801,6 +906,8 @@ int32_t wrk_runtime_create(wrk_ctx* ctx, const wrk_gguf* g, const wrk_build_opti
         for (uint32_t l = 0; l < I.num_layer; ++l) {
             wrk_v6_layer_desc& L = rt->layers6[l];
             const float discount = 1.0f / (float)(1u << std::min<uint32_t>(l / rescale6, 30));
+            layer_quant = opt && opt->quant && l < opt->num_quant ? opt->quant[l] : (uint32_t)WRK_QUANT_NONE;
+            if (layer_quant > WRK_QUANT_NF4) return fail(WRK_E_ARG, "quant[%u] = %u is not a WRK_QUANT_* value", l, layer_quant);
             const std::string blk = "blocks." + std::to_string(l), att = blk + ".att", ffn = blk + ".ffn";
             wrk_buf* vb;
             wrk_matrix* m;
@@ -888,6 +995,8 @@ int32_t wrk_runtime_create(wrk_ctx* ctx, const wrk_gguf* g, const wrk_build_opti
     for (uint32_t l = 0; l < I.num_layer; ++l) {
         wrk_v7_layer_desc& L = rt->layers[l];
         const float discount = 1.0f / (float)(1u << std::min<uint32_t>(l / rescale, 30));      // 2^-(layer / rescale), v7.rs:1090
+        layer_quant = opt && opt->quant && l < opt->num_quant ? opt->quant[l] : (uint32_t)WRK_QUANT_NONE;   // v7.rs:1089
+        if (layer_quant > WRK_QUANT_NF4) return fail(WRK_E_ARG, "quant[%u] = %u is not a WRK_QUANT_* value", l, layer_quant);
         const std::string blk = "blocks." + std::to_string(l), att = blk + ".att", ffn = blk + ".ffn";
         wrk_buf* b;
         wrk_matrix* m;

@@ -34,6 +34,7 @@ MAT = {"F32": 0, "F16": 1, "Q8_0": 8, "Q4_K": 12, "Q5_K": 13, "Q6_K": 14, "INT8"
 MATRIX_EXACT, MATRIX_ROUND_F16 = 0, 1
 WEIGHTS_INLINE, WEIGHTS_INLINE_F16, WEIGHTS_REFERENCE = 0, 1, 2
 RNN_NONE, RNN_LAST, RNN_FULL = -1, 0, 1
+QUANT_NONE, QUANT_INT8, QUANT_NF4 = 0, 1, 2
 
 if not (os.path.exists(LIB_HIP) and os.path.exists(LIB_RT)):
     raise ImportError(
@@ -61,7 +62,7 @@ class ModelInfo(C.Structure):
 
 
 class BuildOptions(C.Structure):
-    _fields_ = [("rescale", C.c_uint32), ("weights", C.c_uint32)]
+    _fields_ = [("rescale", C.c_uint32), ("weights", C.c_uint32), ("quant", C.POINTER(C.c_uint8)), ("num_quant", C.c_uint32)]
 
 
 _P = C.c_void_p
@@ -91,7 +92,8 @@ HIP_SYMBOLS = {
     "wrk_program_launch": (C.c_int32, [_P, _P]),
     "wrk_program_destroy": (C.c_int32, [_P]),
     "wrk_matrix_create": (C.c_int32, [_P, C.c_uint32, C.c_uint32, C.c_uint32, _P, C.c_size_t, C.c_uint32, C.POINTER(_P)]),
-    "wrk_matrix_quantize": (C.c_int32, [_P, C.c_uint32, C.c_uint32, C.c_uint32, _P, C.POINTER(_P)]),
+    "wrk_matrix_quantize": (C.c_int32, [_P, C.c_uint32, C.c_uint32, C.c_uint32, _P, C.POINTER(C.c_float), C.POINTER(_P)]),
+    "wrk_matrix_export": (C.c_int32, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "wrk_matrix_release": (C.c_int32, [_P]),
     "wrk_matrix_stream_bytes": (C.c_size_t, [_P]),
     "wrk_op_matmul": (C.c_int32, [_P, _P, _TP, _TP, C.c_uint32, C.c_int32, C.c_int32]),
@@ -293,6 +295,43 @@ class Matrix:
         h = _P()
         ctx.check(hip.wrk_matrix_create(ctx.h, MAT[kind], k, m, a.ctypes.data_as(_P), a.nbytes, flags, C.byref(h)))
         self.ctx, self.h, self.k, self.m, self.kind = ctx, h, k, m, kind
+
+    @classmethod
+    def _quant(cls, kind: str, matrix: "Buffer", k: int, m: int, levels=None) -> "Matrix":
+        ctx = matrix.ctx
+        h = _P()
+        lv = None
+        if levels is not None:
+            lv = np.ascontiguousarray(levels, np.float32)
+            assert lv.size == 16
+            lv = lv.ctypes.data_as(C.POINTER(C.c_float))
+        ctx.check(hip.wrk_matrix_quantize(ctx.h, MAT[kind], k, m, matrix.h, lv, C.byref(h)))
+        self = cls.__new__(cls)
+        self.ctx, self.h, self.k, self.m, self.kind = ctx, h, k, m, kind
+        return self
+
+    @classmethod
+    def quant_u8(cls, matrix: "Buffer", k: int, m: int) -> "Matrix":
+        """`Matrix::quant_u8` (matrix.rs:211-227): f16 [K, M] buffer -> Int8 matrix, quantised on the device."""
+        return cls._quant("INT8", matrix, k, m)
+
+    @classmethod
+    def quant_nf4(cls, matrix: "Buffer", k: int, m: int) -> "Matrix":
+        """`Matrix::quant_nf4` (matrix.rs:229-249)."""
+        return cls._quant("NF4", matrix, k, m)
+
+    @classmethod
+    def quant_sf4(cls, matrix: "Buffer", k: int, m: int, levels) -> "Matrix":
+        """`Matrix::quant_sf4` (matrix.rs:251-271) with the caller's 16 levels (`Float4Quant::new_student`)."""
+        return cls._quant("NF4", matrix, k, m, levels)
+
+    def export(self) -> np.ndarray:
+        """Int8 / NF4 planes in `wrk_matrix_create`'s layout (codes ++ side table [++ levels])."""
+        n = C.c_size_t()
+        self.ctx.check(hip.wrk_matrix_export(self.h, None, 0, C.byref(n)))
+        out = np.empty(n.value, np.uint8)
+        self.ctx.check(hip.wrk_matrix_export(self.h, out.ctypes.data_as(_P), out.nbytes, C.byref(n)))
+        return out
 
     @property
     def stream_bytes(self) -> int:
@@ -534,8 +573,15 @@ class Runtime:
     """`ModelBuilder::new(&context, reader).build_v7()` -> `v7::Bundle::<f16>::new(model, num_batch)`
     -> `SimpleRuntime::new(bundle)`; `infer(input)` as src/runtime/mod.rs:238-263."""
 
-    def __init__(self, ctx: Context, reader: GgufReader, num_batch: int = 1, weights: int = WEIGHTS_INLINE, rescale: int = 0):
-        opt = BuildOptions(rescale, weights)
+    def __init__(self, ctx: Context, reader: GgufReader, num_batch: int = 1, weights: int = WEIGHTS_INLINE, rescale: int = 0,
+                 quant: Optional[Dict[int, int]] = None):
+        """`quant`: `ModelBuilder::quant`'s layer -> QUANT_* map."""
+        opt = BuildOptions(rescale, weights, None, 0)
+        if quant:
+            q = np.zeros(max(quant) + 1, np.uint8)
+            for l, v in quant.items():
+                q[l] = v
+            opt.quant, opt.num_quant = q.ctypes.data_as(C.POINTER(C.c_uint8)), q.size
         h = _P()
         _host_check(rt.wrk_runtime_create(ctx.h, reader.h, C.byref(opt), num_batch, C.byref(h)))
         self.ctx, self.h, self.num_batch = ctx, h, num_batch
