@@ -141,7 +141,7 @@ int32_t wrk_matrix_create(wrk_ctx* ctx, uint32_t kind, uint32_t k, uint32_t m,
                           const void* data, size_t bytes, uint32_t flags, wrk_matrix** out);
 /* web-rwkv's own formats through wrk_matrix_create (Matrix::Int8 { w, m } / Matrix::Fp4 { w, q, m },
  * matrix.rs:79-130; the direct-load arms loader.rs:808-820, 901-918):
- *   WRK_MAT_INT8: data = u8 codes [K*M] ++ (min, max) f16 pairs, one per 128 flattened elements; K % 128 == 0
+ *   WRK_MAT_INT8: data = u8 codes [K*M] ++ (min, max) f16 pairs, one per 128 flattened elements; K % 16 == 0, K*M % 128 == 0
  *   WRK_MAT_NF4 : data = nibbles [K*M/2] (element 2i in the low nibble) ++ absmax f16, one per 64 flattened
  *                 elements, optionally ++ the 16 f32 levels of `q` (default: the NF4 levels matrix.rs:50-67;
  *                 pass Float4Quant::new_student's for SF4); K % 64 == 0

@@ -33,7 +33,7 @@ def weights(k, m, seed, zero_block=False):
     return w
 
 
-SHAPES = [(128, 5), (256, 64), (768, 33), (2048, 40), (8192, 8)]
+SHAPES = [(128, 5), (256, 64), (320, 64), (768, 33), (2048, 40), (8192, 8)]     # 320: Int8 blocks straddle rows
 
 
 @pytest.mark.parametrize("k,m", SHAPES)
@@ -53,6 +53,14 @@ def test_quant_u8_codes_and_minmax(ctx, k, m):
         t = 255.0 * (v - mm[:, 0]) / (mm[:, 1] - mm[:, 0]) + 0.5
         assert np.all(np.abs(t - np.round(t)) < 1e-3)
     assert mat.stream_bytes == k * m + (k * m // 128) * 4
+    # and the quantised matrix multiplies like the oracle's reconstruction of the DEVICE codes
+    wd = wq.dequantize_int8(codes, minmax).reshape(m, k)
+    x = np.random.default_rng(0).standard_normal(k).astype(np.float16)
+    out = ctx.zeros([m, 1, 1], np.float32)
+    mat.matmul_op(ctx.tensor(x, [k, 1, 1]), out)
+    want = wd.astype(np.float64) @ x.astype(np.float64)
+    bound = 4e-6 * (np.abs(wd).astype(np.float64) @ np.abs(x).astype(np.float64)) + 1e-6
+    assert np.all(np.abs(out.back().reshape(m) - want) <= bound)
 
 
 @pytest.mark.parametrize("k,m", [(64, 3)] + SHAPES)
@@ -119,6 +127,43 @@ def test_matmul_uploaded_planes(ctx, kind, k, m, T, B):
     assert np.all(np.abs(got - want) <= bound), np.abs(got - want).max()
 
 
+@pytest.mark.parametrize("c,r,t", [(2560, 2048, 64), (320, 64, 320)])
+@pytest.mark.parametrize("kind", ["INT8", "NF4"])
+def test_reference_test_shapes(ctx, kind, c, r, t):
+    """The shapes and value ranges of the reference's own test_matmul_int8 / test_matmul_nf4 (ops.rs:3642-3983):
+    matrix and input uniform in [-5, 5) (NF4: normal), quantise on the device, matmul_vec and matmul_mat against
+    the CPU definition; the reference accepts |a - b| <= max(0.01, 0.01 * max|a|,|b|) and codes off by < 2."""
+    rng = np.random.default_rng(42)
+    if kind == "INT8":
+        w = (10.0 * (rng.random((r, c), np.float32) - 0.5)).astype(np.float16)
+    else:
+        w = rng.standard_normal((r, c)).astype(np.float16)
+    x = (10.0 * (rng.random((t, c), np.float32) - 0.5)).astype(np.float16)
+    src = wrk.Buffer(ctx, w.nbytes, w)
+    mat = wrk.Matrix.quant_u8(src, c, r) if kind == "INT8" else wrk.Matrix.quant_nf4(src, c, r)
+    blob = mat.export()
+    n = c * r
+    if kind == "INT8":
+        codes, mm = blob[:n], blob[n:].view(np.float16).reshape(-1, 2)
+        wc, wmm = wq.quantize_int8(w)
+        assert np.array_equal(mm.view(np.uint16), wmm.view(np.uint16))
+        assert np.abs(codes.astype(np.int32) - wc.astype(np.int32)).max() < 2
+        wd = wq.dequantize_int8(codes, mm).reshape(r, c)
+    else:
+        packed, am = blob[: n // 2], blob[n // 2: n // 2 + n // 64 * 2].view(np.float16)
+        wp, wam = wq.quantize_nf4(w)
+        assert np.array_equal(am.view(np.uint16), wam.view(np.uint16)) and np.array_equal(packed, wp)
+        wd = wq.dequantize_nf4(packed, am).reshape(r, c)
+    ans = x.astype(np.float64) @ wd.astype(np.float64).T
+    for turbo in (False, True):
+        out = ctx.zeros([r, t, 1], np.float32)
+        mat.matmul_op(ctx.tensor(x, [c, t, 1]), out, turbo=turbo)
+        got = out.back().reshape(t, r)
+        assert np.all(np.abs(got - ans) <= np.maximum(0.01, 0.01 * np.maximum(np.abs(got), np.abs(ans))))
+        bound = 4e-6 * (np.abs(x).astype(np.float64) @ np.abs(wd).astype(np.float64).T) + 1e-5     # our own, tighter bar
+        assert np.all(np.abs(got - ans) <= bound), np.abs(got - ans).max()
+
+
 def test_repack_q8_0_to_int8_matmul(ctx):
     """loader.rs:808-820: a Q8_0 GGUF tensor loaded under Quant::Int8 is repacked on the host (gguf.rs:429-520)."""
     k, m = 512, 24
@@ -138,7 +183,7 @@ def test_repack_q8_0_to_int8_matmul(ctx):
 
 def test_bad_shapes_rejected(ctx):
     with pytest.raises(wrk.WrkError):
-        wrk.Matrix(ctx, "INT8", 192, 4, np.zeros(192 * 4 + 24, np.uint8))       # K % 128
+        wrk.Matrix(ctx, "INT8", 200, 16, np.zeros(200 * 16 + 100, np.uint8))    # K % 16
     with pytest.raises(wrk.WrkError):
         wrk.Matrix(ctx, "NF4", 128, 4, np.zeros(10, np.uint8))                  # wrong byte count
     w = weights(96, 4, 1)

@@ -245,7 +245,7 @@ int32_t wrk_matrix_create(wrk_ctx* ctx, uint32_t kind, uint32_t k, uint32_t m, c
             expect = wrk::stored_bytes(kind, k, m);
             break;
         case WRK_MAT_INT8:
-            WRK_ARG(ctx, k % 128 == 0, "Int8 matrices need K %% 128 == 0 (INT8_BLOCK_SIZE, ops.rs)");
+            WRK_ARG(ctx, k >= 128 && k % 16 == 0 && ((size_t)k * m) % 128 == 0, "Int8 matrices need K %% 16 == 0 and K*M %% 128 == 0 (INT8_BLOCK_SIZE, ops.rs:36)");
             expect = wrk::stored_bytes(kind, k, m);
             break;
         case WRK_MAT_NF4:
@@ -291,7 +291,7 @@ int32_t wrk_matrix_quantize(wrk_ctx* ctx, uint32_t kind, uint32_t k, uint32_t m,
     WRK_ARG(ctx, k > 0 && m > 0, "matrix dims must be positive");
     if (kind != WRK_MAT_INT8 && kind != WRK_MAT_NF4)
         return wrk_fail(ctx, WRK_E_UNSUPPORTED, "wrk_matrix_quantize: kind %u is not Int8 / NF4", kind);
-    WRK_ARG(ctx, kind != WRK_MAT_INT8 || k % 128 == 0, "Int8 matrices need K %% 128 == 0");
+    WRK_ARG(ctx, kind != WRK_MAT_INT8 || (k >= 128 && k % 16 == 0 && ((size_t)k * m) % 128 == 0), "Int8 matrices need K %% 16 == 0 and K*M %% 128 == 0");
     WRK_ARG(ctx, kind != WRK_MAT_NF4 || k % 64 == 0, "NF4 matrices need K %% 64 == 0");
     WRK_ARG(ctx, f16_data->bytes >= (size_t)k * m * 2, "source holds %zu bytes, [%u x %u] f16 needs %zu", f16_data->bytes, k, m, (size_t)k * m * 2);
     WRK_HIP(ctx, hipSetDevice(ctx->device));
@@ -329,10 +329,16 @@ int32_t wrk_matrix_export(wrk_matrix* mat, void* dst, size_t capacity, size_t* b
     WRK_HIP(ctx, hipMemcpy(host.data(), mat->data, host.size(), hipMemcpyDeviceToHost));
     uint8_t* o = (uint8_t*)dst;
     const size_t code_row = mat->kind == WRK_MAT_INT8 ? k : k / 2;
-    const size_t side_row = mat->kind == WRK_MAT_INT8 ? (size_t)(k / 128) * 4 : (size_t)(k / 64) * 2;
-    for (uint32_t r = 0; r < m; ++r) {
-        memcpy(o + (size_t)r * code_row, host.data() + (size_t)r * mat->row_bytes, code_row);
-        memcpy(o + (size_t)m * code_row + (size_t)r * side_row, host.data() + (size_t)r * mat->row_bytes + code_row, side_row);
+    for (uint32_t r = 0; r < m; ++r) memcpy(o + (size_t)r * code_row, host.data() + (size_t)r * mat->row_bytes, code_row);
+    if (mat->kind == WRK_MAT_INT8) {       // block b lives (at least) in the row holding its first element
+        for (size_t b = 0; b < (size_t)k * m / 128; ++b) {
+            const size_t r = b * 128 / k;
+            memcpy(o + (size_t)m * k + b * 4, host.data() + r * mat->row_bytes + k + (b - r * k / 128) * 4, 4);
+        }
+    } else {
+        const size_t side_row = (size_t)(k / 64) * 2;
+        for (uint32_t r = 0; r < m; ++r)
+            memcpy(o + (size_t)m * code_row + (size_t)r * side_row, host.data() + (size_t)r * mat->row_bytes + code_row, side_row);
     }
     if (mat->kind == WRK_MAT_NF4) WRK_HIP(ctx, hipMemcpy(o + total - 64, mat->aux, 64, hipMemcpyDeviceToHost));
     return WRK_OK;

@@ -95,3 +95,10 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     for (int i = 0; i < NW; ++i) t += red[i];
     return t;
 }
+
+// debug timing (WRK_TIMING=1): thread 0 of the first / last workgroup stamps the 100 MHz wall clock
+#define WRK_STAMP(p, k)                                                                                       \
+    do {                                                                                                      \
+        if ((p) && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))                      \
+            (p)[(blockIdx.x ? 8 : 0) + (k)] = wall_clock64();                                                 \
+    } while (0)

@@ -146,6 +146,10 @@ void gather_rows_f16(hipStream_t s, const void* table, const uint32_t* ids, void
 void gather_rows_any(hipStream_t s, DTensor in, const uint32_t* rows, DTensor out, uint32_t n);
 void argmax_rows(hipStream_t s, const float* logits, uint32_t v, uint32_t v_stride, uint32_t n, uint32_t* out);
 
+// WRK_TIMING=1 (debug): in-kernel wall-clock stamps of one decode layer, printed after wrk_v7_generate_greedy
+unsigned long long* timing_slot(wrk_ctx* ctx, const char* label);   // nullptr unless enabled
+void timing_report(wrk_ctx* ctx);
+
 // wrk_matvec.hip
 struct MatJob {
     const uint8_t* w;       // matrix data (device layout)
@@ -169,9 +173,11 @@ struct MatJob {
     void* ln_out = nullptr;         // f16 [K]: LN(in), published by the first workgroup of the job
     const void* carry_src = nullptr;    // epilogue: carry_dst[row] = carry_src[row]
     float* carry_dst = nullptr;
+    unsigned long long* dbg = nullptr;  // WRK_TIMING=1: 16 device timestamps of this launch (first and last workgroup)
 };
 uint32_t matvec_num_wg(const MatJob* jobs, int njobs, int num_cu, uint32_t* rows_per_wg);
-int matvec(hipStream_t s, const MatJob* jobs, int njobs, int num_cu);
+// dry_run: classify only (0 = a launch would honour every job's prologue / carry request, -3 = it cannot)
+int matvec(hipStream_t s, const MatJob* jobs, int njobs, int num_cu, bool dry_run = false);
 // MFMA dequant-GEMM (wrk_gemm.hip); -2 = not applicable (caller uses the matvec kernels).  xsum_scratch: device
 // f32 buffer of at least tokens * K/32 elements (only the K4 kinds use it)
 int matmul_mfma(hipStream_t s, const MatJob& job, int num_cu, float* xsum_scratch, size_t xsum_cap);
@@ -179,6 +185,7 @@ int matmul_mfma(hipStream_t s, const MatJob& job, int num_cu, float* xsum_scratc
 void quantize_int8(hipStream_t s, const void* src_f16, uint8_t* dst, uint32_t k, uint32_t m, uint32_t row_bytes);
 void quantize_nf4(hipStream_t s, const void* src_f16, const float* levels, uint8_t* dst, uint32_t k, uint32_t m, uint32_t row_bytes);
 size_t repack_row_bytes(uint32_t kind, uint32_t k);
+uint32_t int8_row_blocks(uint32_t k);   // (min, max) entries stored per Int8 row
 int repack_rows(uint32_t kind, uint32_t k, uint32_t m, const uint8_t* src, uint8_t* dst);   // host side
 size_t stored_bytes(uint32_t kind, uint32_t k, uint32_t m);
 

@@ -20,11 +20,16 @@
 //   * wave64 butterfly reduction, fused activation, store in the output buffer's dtype.
 // WRK_MATRIX_ROUND_F16 instead rounds every dequantised weight to f16 first, reproducing the
 // reference at HEAD (weights dequantised to f16 on the CPU at load, gguf.rs:95-274).
+#include <algorithm>
+#include <cstdlib>
+
 #include "wrk_device.h"
 
 namespace wrk {
 
 static inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+uint32_t int8_row_blocks(uint32_t k) { return (k % 128) ? k / 128 + 2 : k / 128; }
 
 size_t repack_row_bytes(uint32_t kind, uint32_t k) {
     const size_t nb = k / 256;
@@ -34,7 +39,9 @@ size_t repack_row_bytes(uint32_t kind, uint32_t k) {
         case WRK_MAT_Q4_K: return align16(nb * 148);   // quants 128 | d,dmin 4 | unpacked 6-bit scales/mins 16
         case WRK_MAT_Q5_K: return align16(nb * 180);   // quants 128 | high bits 32 | d,dmin 4 | scales/mins 16
         case WRK_MAT_Q6_K: return align16(nb * 208 + nb * 2);
-        case WRK_MAT_INT8: return (k % 128) ? 0 : align16((size_t)k + (size_t)(k / 128) * 4);   // codes | (min, max) f16 per 128
+        // codes | (min, max) f16 of every 128-block of the FLATTENED matrix this row touches (k/128 when rows are
+        // block aligned, else up to k/128 + 2: the reference's own test multiplies a K = 320 Int8 matrix, ops.rs:3786)
+        case WRK_MAT_INT8: return (k % 16) ? 0 : align16((size_t)k + (size_t)int8_row_blocks(k) * 4);
         case WRK_MAT_NF4: return (k % 64) ? 0 : align16((size_t)k / 2 + (size_t)(k / 64) * 2);   // nibbles | absmax f16 per 64
         default: return 0;
     }
@@ -121,7 +128,9 @@ int repack_rows(uint32_t kind, uint32_t k, uint32_t m, const uint8_t* src, uint8
             // matrix (Matrix::Int8 { w, m } / Matrix::Fp4 { w, q, m }); k % block == 0 makes the side table per-row
             case WRK_MAT_INT8: {
                 memcpy(d, src + (size_t)r * k, k);
-                memcpy(d + k, src + (size_t)m * k + (size_t)r * (k / 128) * 4, (size_t)(k / 128) * 4);
+                const size_t total = (size_t)k * m / 128, first = (size_t)r * k / 128;
+                const size_t cnt = std::min<size_t>(int8_row_blocks(k), total - first);
+                memcpy(d + k, src + (size_t)m * k + first * 4, cnt * 4);
                 break;
             }
             case WRK_MAT_NF4: {
@@ -232,6 +241,7 @@ struct JobDev {
     // optional fused shift-state carry in the epilogue: carry_dst[row] = carry_src[row] (channel_mix_v7's state write)
     const f16* carry_src;
     float* carry_dst;
+    unsigned long long* dbg;
 };
 
 struct MatvecParams {
@@ -258,7 +268,7 @@ __device__ __forceinline__ uint32_t num_chunks(uint32_t k, uint32_t kpad) {
 }
 
 template <int KIND>
-__device__ __forceinline__ Raw load_raw(const uint8_t* __restrict__ row, uint32_t k, uint32_t c) {
+__device__ __forceinline__ Raw load_raw(const uint8_t* __restrict__ row, uint32_t k, uint32_t c, uint32_t phase = 0) {
     Raw r;
     r.w = __builtin_nontemporal_load((const u32x4*)(row + (size_t)c * 16));
     const uint32_t nb = k >> 8, b = c >> 3;
@@ -278,7 +288,7 @@ __device__ __forceinline__ Raw load_raw(const uint8_t* __restrict__ row, uint32_
     } else if (KIND == WRK_MAT_Q8_0) {
         r.a.x = *(const uint16_t*)(row + (size_t)k + (size_t)(c >> 1) * 2);
     } else if (KIND == WRK_MAT_INT8) {
-        r.a.x = *(const uint32_t*)(row + (size_t)k + (size_t)(c >> 3) * 4);          // (min, max) f16 of the 128-block
+        r.a.x = *(const uint32_t*)(row + (size_t)k + (size_t)((c + phase) >> 3) * 4);   // (min, max) f16 of the 128-block
     } else if (KIND == WRK_MAT_NF4) {
         r.a.x = *(const uint16_t*)(row + (size_t)(k >> 1) + (size_t)(c >> 1) * 2);   // absmax f16 of the 64-block
     }
@@ -459,53 +469,6 @@ __device__ __forceinline__ XRegs load_x(const f16* __restrict__ x, uint32_t c, b
     return r;
 }
 
-// LN statistics of a dense f16 row, computed by ONE wave (every wave of a launch does this redundantly: the row is
-// a few KB and L2 resident, and the two reductions are DPP-only).  Two passes over the row (second pass hits L1).
-__device__ __forceinline__ void wave_ln_stats(const f16* __restrict__ x, uint32_t d, float eps, uint32_t lane, float& mean, float& dev) {
-    const uint32_t nvec = d >> 3;
-    float s = 0.0f;
-    for (uint32_t v = lane; v < nvec; v += 64) s += sum8(*(const f16x8*)(x + v * 8));
-    mean = wave_sum(s) / (float)d;
-    float q = 0.0f;
-    for (uint32_t v = lane; v < nvec; v += 64) {
-        const f16x8 xv = *(const f16x8*)(x + v * 8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { const float dl = (float)xv[e] - mean; q += dl * dl; }
-    }
-    dev = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
-}
-
-// x_in[off..off+8) = f16(mix(f16(LN(x)), prev, mixw))
-__device__ __forceinline__ f16x8 ln_mix8(const JobDev& J, const f16* __restrict__ x, uint32_t off, float mean, float dev, f16x8* ln_only) {
-    const f16x8 xv = *(const f16x8*)(x + off), wv = *(const f16x8*)(J.ln_w + off), bv = *(const f16x8*)(J.ln_b + off);
-    f16x8 y, o;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) y[e] = (f16)__builtin_fmaf(((float)xv[e] - mean) * dev, (float)wv[e], (float)bv[e]);
-    if (ln_only) { *ln_only = y; return y; }
-    const f16x8 mv = *(const f16x8*)(J.mixw + off);
-    const f32x4 p0 = *(const f32x4*)(J.prev + off), p1 = *(const f32x4*)(J.prev + off + 4);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (f16)wgsl_mix((float)y[e], e < 4 ? p0[e & 3] : p1[e & 3], (float)mv[e]);
-    return o;
-}
-
-template <int KIND>
-__device__ __forceinline__ XRegs load_x_pro(const JobDev& J, const f16* __restrict__ x, uint32_t c, bool valid, float mean, float dev) {
-    XRegs r;
-    const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-    r.v[0] = r.v[1] = r.v[2] = r.v[3] = z;
-    r.s[0] = r.s[1] = 0.0f;
-    if (!valid) return r;
-    uint32_t lo, hi;
-    chunk_xoff<KIND>(c, lo, hi);
-    r.v[0] = ln_mix8(J, x, lo, mean, dev, nullptr);
-    if (KIND != WRK_MAT_F16) r.v[1] = ln_mix8(J, x, lo + 8, mean, dev, nullptr);
-    if (KIND != WRK_MAT_F16 && KIND != WRK_MAT_Q8_0) { r.v[2] = ln_mix8(J, x, hi, mean, dev, nullptr); r.v[3] = ln_mix8(J, x, hi + 8, mean, dev, nullptr); }
-    if (KIND != WRK_MAT_F16) r.s[0] = sum8(r.v[0]) + sum8(r.v[1]);
-    if (KIND != WRK_MAT_F16 && KIND != WRK_MAT_Q8_0) r.s[1] = sum8(r.v[2]) + sum8(r.v[3]);
-    return r;
-}
-
 __device__ __forceinline__ float dot16r(const f16x2 (&q)[8], const f16x8 xa, const f16x8 xb) {
     float acc = 0.0f;
     acc = __builtin_amdgcn_fdot2(q[0], __builtin_shufflevector(xa, xa, 0, 1), acc, false);
@@ -571,7 +534,12 @@ __device__ __forceinline__ void matvec_body(const JobDev& J, unsigned char* smem
         const uint32_t c = lane + 64 * ci;
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
-            if (ri0 + rb < nrows && c < nch) raw[rb] = load_raw<KIND>(J.w + (size_t)(r0 + wave + 4 * (ri0 + rb)) * J.row_bytes, K, c);
+            if (ri0 + rb < nrows && c < nch) {
+                const uint32_t r = r0 + wave + 4 * (ri0 + rb);
+                // Int8 blocks run over the flattened matrix: the row starts `phase` 16-element chunks into a block
+                const uint32_t phase = KIND == WRK_MAT_INT8 ? (uint32_t)((((size_t)r * K) >> 4) & 7u) : 0u;
+                raw[rb] = load_raw<KIND>(J.w + (size_t)r * J.row_bytes, K, c, phase);
+            }
     };
     // request the first chunks before touching the inputs: weights do not depend on activations
     issue(0, 0);
@@ -677,7 +645,9 @@ __device__ __forceinline__ void matvec_body(const JobDev& J, unsigned char* smem
 //            ALL rows of the workgroup; the four partial sums per row meet in LDS once, at the end.
 template <int KIND, bool R16, int XI, int KS>
 __device__ __forceinline__ void matvec_body_reg(const JobDev& J, unsigned char* smem) {
-    constexpr int RB = KIND == WRK_MAT_F16 ? 4 : 2;
+    // rows in flight per wave: everything a wave owns (<= 4 rows for <= 16 rows per workgroup) goes out in ONE round
+    // trip -- the in-kernel timeline (WRK_TIMING) showed a second trip costs 1.2 us, a third of the kernel
+    constexpr int RB = 4;
     static_assert(KS == 1 || XI == 1, "K-split uses one chunk iteration per wave");
     const uint32_t K = J.k;
     const uint32_t kpad = (K + 15u) & ~15u;
@@ -699,29 +669,93 @@ __device__ __forceinline__ void matvec_body_reg(const JobDev& J, unsigned char* 
                 if (ri0 + rb < nrows && c < nch) raw[rb][ci] = load_raw<KIND>(J.w + (size_t)row_of(ri0 + rb) * J.row_bytes, K, c);
             }
     };
+    WRK_STAMP(J.dbg, 0);
     issue(0);       // weights first: they do not depend on the activations
     const f16* xin = (const f16*)J.in.p + dt_index(J.in, 0, 0, 0);
     XRegs x[XI];
     if (J.pro) {
-        float mean, dev;
-        wave_ln_stats(xin, K, J.pro_eps, lane, mean, dev);
+        // Fused layer_norm + token_shift prologue, computed ONCE per workgroup: thread t owns elements 8t..8t+7 (and
+        // +2048), every global vector (row, LN weight/bias, shift state, mix factor) is requested up front, the two
+        // statistics are block reductions, and the shifted f16 input is handed to the waves through LDS.
+        constexpr int VPT = 2;                                  // K <= 4096
+        f16* xs = (f16*)(smem + 576);
+        float* red = (float*)(smem + 544);     // 8 floats
+        const uint32_t nvec = K >> 3;
+        f16x8 xv[VPT], wv[VPT], bv[VPT], mv[VPT];
+        f32x4 pv[VPT][2];
 #pragma unroll
-        for (int ci = 0; ci < XI; ++ci) x[ci] = load_x_pro<KIND>(J, xin, cbase + 64 * ci, cbase + 64 * ci < nch, mean, dev);
-        if (J.ln_out && blockIdx.x == J.wg_begin)       // one workgroup publishes LN(x) for the state carry
-            for (uint32_t v = tid; v < (K >> 3); v += 256) { f16x8 y; ln_mix8(J, xin, v * 8, mean, dev, &y); *(f16x8*)(J.ln_out + v * 8) = y; }
+        for (int v = 0; v < VPT; ++v) {
+            const uint32_t i = tid + 256 * v;
+            if (i < nvec) {
+                xv[v] = *(const f16x8*)(xin + i * 8);
+                wv[v] = *(const f16x8*)(J.ln_w + i * 8);
+                bv[v] = *(const f16x8*)(J.ln_b + i * 8);
+                mv[v] = *(const f16x8*)(J.mixw + i * 8);
+                pv[v][0] = *(const f32x4*)(J.prev + i * 8);
+                pv[v][1] = *(const f32x4*)(J.prev + i * 8 + 4);
+            }
+        }
+        // one pass, one block reduction: sums of (x - c) and (x - c)^2 around c = x[0] (any constant is exact in
+        // infinite precision; a value of the row keeps the cancellation of E[d^2] - E[d]^2 harmless)
+        const float c0 = (float)xin[0];
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int v = 0; v < VPT; ++v)
+            if (tid + 256 * v < nvec)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float dl = (float)xv[v][e] - c0; s1 += dl; s2 = __builtin_fmaf(dl, dl, s2); }
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        if (lane == 0) { red[wave] = s1; red[4 + wave] = s2; }
+        __syncthreads();
+        s1 = (red[0] + red[1]) + (red[2] + red[3]);
+        s2 = (red[4] + red[5]) + (red[6] + red[7]);
+        const float md = s1 / (float)K;
+        const float mean = c0 + md;
+        const float dev = 1.0f / sqrtf(fmaxf(s2 / (float)K - md * md, 0.0f) + J.pro_eps);
+        const bool publish = J.ln_out && blockIdx.x == J.wg_begin;      // one workgroup stores LN(x) for the state carry
+#pragma unroll
+        for (int v = 0; v < VPT; ++v) {
+            const uint32_t i = tid + 256 * v;
+            if (i >= nvec) continue;
+            f16x8 yv, o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                yv[e] = (f16)__builtin_fmaf(((float)xv[v][e] - mean) * dev, (float)wv[v][e], (float)bv[v][e]);
+                o[e] = (f16)wgsl_mix((float)yv[e], pv[v][e >> 2][e & 3], (float)mv[v][e]);
+            }
+            *(f16x8*)(xs + i * 8) = o;
+            if (publish) *(f16x8*)(J.ln_out + i * 8) = yv;
+        }
+        for (uint32_t i = K + tid; i < kpad; i += 256) xs[i] = (f16)0.0f;
+        __syncthreads();
+#pragma unroll
+        for (int ci = 0; ci < XI; ++ci) x[ci] = load_x<KIND>(xs, cbase + 64 * ci, cbase + 64 * ci < nch);
     } else {
 #pragma unroll
         for (int ci = 0; ci < XI; ++ci) x[ci] = load_x<KIND>(xin, cbase + 64 * ci, cbase + 64 * ci < nch);
     }
 
+    WRK_STAMP(J.dbg, 1);                        // inputs (and prologue) done
     float* part = (float*)smem;                 // KS == 4: [32 rows][4 waves]
     float best_v = -3.0e38f;
     uint32_t best_i = 0xffffffffu;
-    auto finish = [&](uint32_t r, float v) {    // activation, fused residual, store, running arg-max
+    // residual / carry operands of the rows this thread will finish: requested now, with everything else, so the
+    // epilogue does not start another memory round trip
+    float res_pre[RB], carry_pre[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        res_pre[rb] = carry_pre[rb] = 0.0f;
+        const uint32_t r = KS == 1 ? row_of(rb) : r0 + tid;
+        const bool mine = KS == 1 ? (uint32_t)rb < nrows : (rb == 0 && tid < nrows);
+        if (mine && J.has_res) res_pre[rb] = dt_load(J.res, dt_index(J.res, r, 0, 0));
+        if (mine && J.carry_dst) carry_pre[rb] = (float)J.carry_src[r];
+    }
+    auto finish = [&](uint32_t r, float v, float resv, float carryv) {    // activation, fused residual, store, running arg-max
         float o = act_apply(J.act, v);
-        if (J.has_res) o = dt_round(J.out, o) + dt_load(J.res, dt_index(J.res, r, 0, 0));
+        if (J.has_res) o = dt_round(J.out, o) + resv;
         dt_store(J.out, dt_index(J.out, r, 0, 0), o);
-        if (J.carry_dst) J.carry_dst[r] = (float)J.carry_src[r];
+        if (J.carry_dst) J.carry_dst[r] = carryv;
         if (o > best_v || (o == best_v && r < best_i)) { best_v = o; best_i = r; }
     };
     for (uint32_t ri0 = 0; ri0 < nrows; ri0 += RB) {
@@ -736,20 +770,29 @@ __device__ __forceinline__ void matvec_body_reg(const JobDev& J, unsigned char* 
                 if (ri0 + rb < nrows && c < nch) acc[rb] += dot_raw_reg<KIND, R16>(raw[rb][ci], c, x[ci]);
             }
         }
+        WRK_STAMP(J.dbg, 2);                    // weights arrived, dots done
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
             if (ri0 + rb >= nrows) break;
             const float v = wave_sum(acc[rb]);
             if (lane == 0) {
-                if (KS == 1) finish(row_of(ri0 + rb), v);
-                else part[(ri0 + rb) * 4 + wave] = v;
+                if (KS == 1) {
+                    const uint32_t r = row_of(ri0 + rb);
+                    float resv = res_pre[rb], carryv = carry_pre[rb];
+                    if (ri0 != 0) {     // rows beyond the first batch (more than 4 per wave): load on demand
+                        if (J.has_res) resv = dt_load(J.res, dt_index(J.res, r, 0, 0));
+                        if (J.carry_dst) carryv = (float)J.carry_src[r];
+                    }
+                    finish(r, v, resv, carryv);
+                } else part[(ri0 + rb) * 4 + wave] = v;
             }
         }
     }
     if (KS == 4) {
         __syncthreads();
-        if (tid < nrows) finish(r0 + tid, (part[tid * 4] + part[tid * 4 + 1]) + (part[tid * 4 + 2] + part[tid * 4 + 3]));
+        if (tid < nrows) finish(r0 + tid, (part[tid * 4] + part[tid * 4 + 1]) + (part[tid * 4 + 2] + part[tid * 4 + 3]), res_pre[0], carry_pre[0]);
     }
+    WRK_STAMP(J.dbg, 3);
     if (J.amax_val) {       // fused greedy sampling, stage 1 (uniform branch: every wave of the launch takes it)
         float* sv = (float*)(smem + 512);
         uint32_t* si = (uint32_t*)(smem + 528);
@@ -776,7 +819,7 @@ __device__ __forceinline__ void matvec_body_reg(const JobDev& J, unsigned char* 
 
 template <int KA, int KB, bool R16, int XI, int KS>
 __global__ void __launch_bounds__(256) matvec_reg_kernel(const MatvecParams P) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[576];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[576 + 2 * 4096];   // partials | arg-max | LN scratch | staged input (prologue)
     int ji = 0;
 #pragma unroll
     for (int q = 1; q < MAX_JOBS; ++q)
@@ -859,6 +902,7 @@ static matvec_fn pick_reg(const MatvecParams& P, int quant, bool has_f16, bool r
     for (int j = 0; j < P.njobs; ++j) {
         const JobDev& J = P.jobs[j];
         if (J.in.dtype != WRK_F16 || (J.k & 7u) || J.in.shape[1] * J.in.shape[2] != 1) return nullptr;
+        if (J.pro && J.k > 4096) return nullptr;        // the staged input of the LN prologue is sized for K <= 4096
         const size_t base = ((size_t)J.in.offset[2] * J.in.stride[1] + J.in.offset[1]) * J.in.stride[0] + J.in.offset[0];
         if (base & 7u) return nullptr;
         const uint32_t kpad = (J.k + 15u) & ~15u;
@@ -883,7 +927,7 @@ static matvec_fn pick_reg(const MatvecParams& P, int quant, bool has_f16, bool r
 }
 
 template <int NB>
-static int launch_matvec(hipStream_t s, const MatvecParams& P, uint32_t total_wg, uint32_t tok_groups, size_t smem) {
+static int launch_matvec(hipStream_t s, const MatvecParams& P, uint32_t total_wg, uint32_t tok_groups, size_t smem, bool dry) {
     // classify the kinds of this launch
     int quant = -1, nquant = 0;
     bool has_f16 = false, r16 = false, mixed_r16 = false;
@@ -900,11 +944,12 @@ static int launch_matvec(hipStream_t s, const MatvecParams& P, uint32_t total_wg
     if (NB == 1 && tok_groups == 1 && nquant <= 1 && !mixed_r16) {
         fn = pick_reg(P, nquant ? quant : -1, has_f16, r16);
         if (fn) {
-            hipLaunchKernelGGL(fn, dim3(total_wg, 1), dim3(256), 0, s, P);
+            if (!dry) hipLaunchKernelGGL(fn, dim3(total_wg, 1), dim3(256), 0, s, P);
             return 0;
         }
     }
     if (needs_reg) return -3;
+    if (dry) return 0;
     if (nquant >= 2 || mixed_r16) fn = (matvec_fn)matvec_kernel<NB, -1, -1, false>;
     else if (nquant == 0) fn = pick_kernel<NB>(WRK_MAT_F16, WRK_MAT_F16, false);
     else fn = pick_kernel<NB>(quant, has_f16 ? WRK_MAT_F16 : quant, r16);
@@ -915,6 +960,16 @@ static int launch_matvec(hipStream_t s, const MatvecParams& P, uint32_t total_wg
     return 0;
 }
 
+// Rows per workgroup of job j: `rpw` for the lightest rows of the launch, fewer for heavier rows so that every
+// workgroup moves about the same bytes (an F16 LoRA row is 3.5x a Q4_K row of the same K: with equal row counts the
+// F16 workgroups were the stragglers of the launch, WRK_TIMING round 1).
+static uint32_t matvec_job_rpw(const MatJob* jobs, int njobs, int j, uint32_t rpw) {
+    uint32_t min_rb = jobs[0].row_bytes;
+    for (int q = 1; q < njobs; ++q) min_rb = jobs[q].row_bytes < min_rb ? jobs[q].row_bytes : min_rb;
+    uint32_t r = (uint32_t)((uint64_t)rpw * min_rb / (jobs[j].row_bytes ? jobs[j].row_bytes : 1)) & ~3u;
+    return r < 4 ? 4 : r;
+}
+
 uint32_t matvec_num_wg(const MatJob* jobs, int njobs, int num_cu, uint32_t* rows_per_wg) {
     uint32_t total_rows = 0;
     for (int j = 0; j < njobs; ++j) total_rows += jobs[j].m;
@@ -922,14 +977,18 @@ uint32_t matvec_num_wg(const MatJob* jobs, int njobs, int num_cu, uint32_t* rows
     uint32_t rpw = (total_rows + (uint32_t)num_cu * 4 - 1) / ((uint32_t)num_cu * 4);
     rpw = (rpw + 3) & ~3u;
     rpw = rpw < 4 ? 4 : (rpw > 32 ? 32 : rpw);
+    // a launch with the LN prologue pays ~6 vector loads + two block reductions per workgroup: amortise over more rows
+    static const uint32_t pro_rpw = [] { const char* e = getenv("WRK_PRO_RPW"); const int v = e ? atoi(e) : 16; return (uint32_t)(v < 4 ? 4 : (v > 32 ? 32 : v)) & ~3u; }();
+    for (int j = 0; j < njobs; ++j)
+        if (jobs[j].pro && rpw < pro_rpw) rpw = pro_rpw;
     uint32_t wg = 0;
-    for (int j = 0; j < njobs; ++j) wg += (jobs[j].m + rpw - 1) / rpw;
+    for (int j = 0; j < njobs; ++j) { const uint32_t r = matvec_job_rpw(jobs, njobs, j, rpw); wg += (jobs[j].m + r - 1) / r; }
     if (rows_per_wg) *rows_per_wg = rpw;
     return wg;
 }
 
 // All jobs of one call must have the same number of input vectors (T*B); they run in ONE launch.
-int matvec(hipStream_t s, const MatJob* jobs, int njobs, int num_cu) {
+int matvec(hipStream_t s, const MatJob* jobs, int njobs, int num_cu, bool dry_run) {
     if (njobs <= 0 || njobs > MAX_JOBS) return -1;
     MatvecParams P;
     P.njobs = njobs;
@@ -946,13 +1005,13 @@ int matvec(hipStream_t s, const MatJob* jobs, int njobs, int num_cu) {
     for (int j = 0; j < njobs; ++j) {
         JobDev& d = P.jobs[j];
         d.w = jobs[j].w; d.aux = (const float*)jobs[j].aux; d.kind = jobs[j].kind; d.flags = jobs[j].flags; d.k = jobs[j].k; d.m = jobs[j].m;
-        d.row_bytes = jobs[j].row_bytes; d.act = jobs[j].act; d.rows_per_wg = rpw; d.wg_begin = wg;
+        d.row_bytes = jobs[j].row_bytes; d.act = jobs[j].act; d.rows_per_wg = matvec_job_rpw(jobs, njobs, j, rpw); d.wg_begin = wg;
         d.in = jobs[j].in; d.out = jobs[j].out; d.res = jobs[j].res; d.has_res = jobs[j].has_res;
         d.amax_val = jobs[j].amax_val; d.amax_idx = jobs[j].amax_idx;
         d.pro = jobs[j].pro; d.pro_eps = jobs[j].pro_eps; d.ln_w = (const f16*)jobs[j].ln_w; d.ln_b = (const f16*)jobs[j].ln_b;
         d.mixw = (const f16*)jobs[j].mixw; d.prev = jobs[j].prev; d.ln_out = (f16*)jobs[j].ln_out;
-        d.carry_src = (const f16*)jobs[j].carry_src; d.carry_dst = jobs[j].carry_dst;
-        wg += (jobs[j].m + rpw - 1) / rpw;
+        d.carry_src = (const f16*)jobs[j].carry_src; d.carry_dst = jobs[j].carry_dst; d.dbg = jobs[j].dbg;
+        wg += (jobs[j].m + d.rows_per_wg - 1) / d.rows_per_wg;
     }
     const uint32_t kpad = (kmax + 15u) & ~15u;
     // pick inputs-per-pass: LDS budget 144 KiB
@@ -962,10 +1021,10 @@ int matvec(hipStream_t s, const MatJob* jobs, int njobs, int num_cu) {
     if (smem < 256) smem = 256;
     const uint32_t groups = (ntok + nb - 1) / nb;
     switch (nb) {
-        case 8: return launch_matvec<8>(s, P, wg, groups, smem);
-        case 4: return launch_matvec<4>(s, P, wg, groups, smem);
-        case 2: return launch_matvec<2>(s, P, wg, groups, smem);
-        default: return launch_matvec<1>(s, P, wg, groups, smem);
+        case 8: return launch_matvec<8>(s, P, wg, groups, smem, dry_run);
+        case 4: return launch_matvec<4>(s, P, wg, groups, smem, dry_run);
+        case 2: return launch_matvec<2>(s, P, wg, groups, smem, dry_run);
+        default: return launch_matvec<1>(s, P, wg, groups, smem, dry_run);
     }
 }
 

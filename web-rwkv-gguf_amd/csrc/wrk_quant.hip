@@ -23,10 +23,11 @@ __global__ void __launch_bounds__(256) quant_int8_kernel(const f16* __restrict__
                                                          uint32_t row_bytes) {
     const uint32_t lane = threadIdx.x & 63;
     const size_t blk = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const uint32_t bpr = k / 128;
-    if (blk >= (size_t)bpr * m) return;
-    const uint32_t row = (uint32_t)(blk / bpr), bi = (uint32_t)(blk % bpr);
-    const f16x2 v = *(const f16x2*)(src + (size_t)row * k + (size_t)bi * 128 + 2 * lane);
+    if (blk >= (size_t)k * m / 128) return;
+    // blocks run over the flattened matrix; k % 16 == 0, so this lane's element pair stays inside one row
+    const size_t e0 = blk * 128 + 2 * lane;
+    const uint32_t row = (uint32_t)(e0 / k), col = (uint32_t)(e0 % k);
+    const f16x2 v = *(const f16x2*)(src + e0);
     const float v0 = (float)v[0], v1 = (float)v[1];
     const float mn = wave_min_f(fminf(v0, v1)), mx = wave_max_f(fmaxf(v0, v1));   // exact f16 values
     const float range = mx - mn;
@@ -34,10 +35,13 @@ __global__ void __launch_bounds__(256) quant_int8_kernel(const f16* __restrict__
     const float x0 = fminf(fmaxf((v0 - mn) / range, 0.0f), 1.0f), x1 = fminf(fmaxf((v1 - mn) / range, 0.0f), 1.0f);
     uint8_t* d = dst + (size_t)row * row_bytes;
     uint8_t c[2] = {(uint8_t)floorf(0.5f + 255.0f * x0), (uint8_t)floorf(0.5f + 255.0f * x1)};
-    *(uint16_t*)(d + (size_t)bi * 128 + 2 * lane) = (uint16_t)c[0] | ((uint16_t)c[1] << 8);
-    if (lane == 0) {
-        f16x2 mm = {(f16)mn, (f16)mx};
-        *(f16x2*)(d + k + (size_t)bi * 4) = mm;
+    *(uint16_t*)(d + col) = (uint16_t)c[0] | ((uint16_t)c[1] << 8);
+    // every row the block touches keeps its own copy of (min, max): entry = block - first block of that row
+    const uint32_t row_last = (uint32_t)((blk * 128 + 127) / k);
+    if (lane == 0 || (lane == 63 && row_last != (uint32_t)(blk * 128 / k))) {
+        const uint32_t rr = lane == 0 ? (uint32_t)(blk * 128 / k) : row_last;
+        const f16x2 mm = {(f16)mn, (f16)mx};
+        *(f16x2*)(dst + (size_t)rr * row_bytes + k + (blk - (size_t)rr * k / 128) * 4) = mm;
     }
 }
 
@@ -69,7 +73,7 @@ __global__ void __launch_bounds__(256) quant_nf4_kernel(const f16* __restrict__ 
 }
 
 void quantize_int8(hipStream_t s, const void* src_f16, uint8_t* dst, uint32_t k, uint32_t m, uint32_t row_bytes) {
-    const size_t blocks = (size_t)(k / 128) * m;
+    const size_t blocks = (size_t)k * m / 128;
     hipLaunchKernelGGL(quant_int8_kernel, dim3((unsigned)((blocks + 3) / 4)), dim3(256), 0, s, (const f16*)src_f16, dst, k, m, row_bytes);
 }
 void quantize_nf4(hipStream_t s, const void* src_f16, const float* levels, uint8_t* dst, uint32_t k, uint32_t m, uint32_t row_bytes) {

@@ -432,6 +432,7 @@ int32_t wrk_v7_generate_greedy(wrk_ctx* ctx, wrk_v7_model* m, wrk_v7_state* st, 
     // WRK_NO_GRAPH=1 enqueues every step eagerly instead (used under rocprofv3 kernel tracing).
     const char* ng = getenv("WRK_NO_GRAPH");
     const bool eager = ng && ng[0] == '1';
+    wrk::timing_slot(ctx, nullptr);     // WRK_TIMING=1: allocate the stamp buffer outside the capture
     auto enqueue_step = [&]() -> int32_t {
         if (mode == 1) return m->enqueue_fused_decode(st, B, B, true, true, true, true, 0);
         wrk::gather_rows_f16(ctx->stream, m->emb->ptr, m->s.tokens, m->s.input, D, B);
@@ -476,6 +477,7 @@ int32_t wrk_v7_generate_greedy(wrk_ctx* ctx, wrk_v7_model* m, wrk_v7_state* st, 
     if (out_tokens) WRK_HIP(ctx, hipMemcpyAsync(out_tokens, m->history, (size_t)steps * B * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (last_logits) WRK_HIP(ctx, hipMemcpyAsync(last_logits, m->s.head_o, (size_t)B * V * 4, hipMemcpyDeviceToHost, ctx->stream));
     WRK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    wrk::timing_report(ctx);
     return WRK_OK;
 }
 

@@ -156,27 +156,36 @@ struct HeadParams {
     const uint32_t* cursors;
     const f16* shift_src;                       // optional [T][D]: copied into state row 0 (att shift carry of a fused K0)
     float gn_eps, l2_eps;
+    uint32_t batch1;                            // batch id + 1 when the host knows it (single-sequence decode), else 0: read the cursor
+    unsigned long long* dbg;
 };
 
 // dot of a row slice of an f16 [D][rank] matrix with the token's f16 LoRA intermediate; 4 lanes share a
-// row (lane `part` takes columns part*8 + 32*n ..+8).  Weights and inputs are loaded together (no LDS).
+// row (lane `part` takes columns part*8 + 32*n ..+8).  Loads and arithmetic are separate calls so the kernel
+// can put EVERY load of the launch in flight before the first wait (loads return in issue order).
 template <int MAXCH>
-__device__ __forceinline__ float lora_row_dot(const f16* __restrict__ wrow, const f16* __restrict__ aux, uint32_t rank, uint32_t part) {
-    f16x8 w[MAXCH], x[MAXCH];
+struct LoraRegs { f16x8 w[MAXCH], x[MAXCH]; };
+
+template <int MAXCH>
+__device__ __forceinline__ void lora_load(LoraRegs<MAXCH>& r, const f16* __restrict__ wrow, const f16* __restrict__ aux, uint32_t rank, uint32_t part) {
 #pragma unroll
     for (int n = 0; n < MAXCH; ++n) {
         const uint32_t c = part * 8 + 32 * n;
-        if (c < rank) { w[n] = *(const f16x8*)(wrow + c); x[n] = *(const f16x8*)(aux + c); }
+        if (c < rank) { r.w[n] = *(const f16x8*)(wrow + c); r.x[n] = *(const f16x8*)(aux + c); }
     }
+}
+
+template <int MAXCH>
+__device__ __forceinline__ float lora_dot(const LoraRegs<MAXCH>& r, uint32_t rank, uint32_t part) {
     float acc = 0.0f;
 #pragma unroll
     for (int n = 0; n < MAXCH; ++n) {
         const uint32_t c = part * 8 + 32 * n;
         if (c < rank) {
-            acc = __builtin_amdgcn_fdot2(__builtin_shufflevector(w[n], w[n], 0, 1), __builtin_shufflevector(x[n], x[n], 0, 1), acc, false);
-            acc = __builtin_amdgcn_fdot2(__builtin_shufflevector(w[n], w[n], 2, 3), __builtin_shufflevector(x[n], x[n], 2, 3), acc, false);
-            acc = __builtin_amdgcn_fdot2(__builtin_shufflevector(w[n], w[n], 4, 5), __builtin_shufflevector(x[n], x[n], 4, 5), acc, false);
-            acc = __builtin_amdgcn_fdot2(__builtin_shufflevector(w[n], w[n], 6, 7), __builtin_shufflevector(x[n], x[n], 6, 7), acc, false);
+            acc = __builtin_amdgcn_fdot2(__builtin_shufflevector(r.w[n], r.w[n], 0, 1), __builtin_shufflevector(r.x[n], r.x[n], 0, 1), acc, false);
+            acc = __builtin_amdgcn_fdot2(__builtin_shufflevector(r.w[n], r.w[n], 2, 3), __builtin_shufflevector(r.x[n], r.x[n], 2, 3), acc, false);
+            acc = __builtin_amdgcn_fdot2(__builtin_shufflevector(r.w[n], r.w[n], 4, 5), __builtin_shufflevector(r.x[n], r.x[n], 4, 5), acc, false);
+            acc = __builtin_amdgcn_fdot2(__builtin_shufflevector(r.w[n], r.w[n], 6, 7), __builtin_shufflevector(r.x[n], r.x[n], 6, 7), acc, false);
         }
     }
     acc += __shfl_xor(acc, 1, WAVE);
@@ -184,36 +193,48 @@ __device__ __forceinline__ float lora_row_dot(const f16* __restrict__ wrow, cons
     return acc;
 }
 
+template <int GCH>     // 32-column chunks of the gate LoRA held per lane group: rank_g <= 32 * GCH
 __global__ void __launch_bounds__(256) head_kernel(const HeadParams P) {
     constexpr int S = 64;
     __shared__ float sh_r[S], sh_w[S], sh_k[S], sh_v[S], sh_a[S], sh_b[S], sh_g[S], sh_kk[S];
     __shared__ float sh_red[4][S];
     const uint32_t head = blockIdx.x, t = blockIdx.y, tid = threadIdx.x;
     const uint32_t D = P.d;
-    const uint32_t batch = P.cursors[t] & 0xffu;
     const uint32_t c0 = head * S;
     const uint32_t i = tid & 63, g4 = tid >> 6;
+    WRK_STAMP(P.dbg, 0);
 
-    // state of this thread's column slice: S[16*g4 .. +15][i] -- requested first, consumed last
+    // (1) everything that does not depend on the cursor goes out first: LoRA up-projection rows for the 64 channels
+    //     of this head (thread = (row = tid/4, part = tid%4)) and the per-channel scalars
+    const uint32_t row = tid >> 2, part = tid & 3u, ch = c0 + row;
+    LoraRegs<4> lw, la, lv;
+    LoraRegs<GCH> lg;
+    lora_load<4>(lw, (const f16*)((const uint8_t*)P.w2 + (size_t)ch * P.w2_rb), P.aux_w + (size_t)t * P.rw, P.rw, part);
+    lora_load<4>(la, (const f16*)((const uint8_t*)P.a2 + (size_t)ch * P.a2_rb), P.aux_a + (size_t)t * P.ra, P.ra, part);
+    lora_load<GCH>(lg, (const f16*)((const uint8_t*)P.g2 + (size_t)ch * P.g2_rb), P.aux_g + (size_t)t * P.rg, P.rg, part);
+    if (!P.layer0) lora_load<4>(lv, (const f16*)((const uint8_t*)P.v2 + (size_t)ch * P.v2_rb), P.aux_v + (size_t)t * P.rv, P.rv, part);
+    const float w0 = (float)P.w0[ch], a0 = (float)P.a0[ch], kkw = (float)P.k_k[ch], kaw = (float)P.k_a[ch];
+    const float kraw = (float)P.k[(size_t)t * D + ch], rraw = (float)P.r[(size_t)t * D + ch];
+    float v = (float)P.v[(size_t)t * D + ch];
+    float v0w = 0.0f, vfirst = 0.0f;
+    if (!P.layer0) { v0w = (float)P.v0[ch]; vfirst = (float)P.v_first[(size_t)t * D + ch]; }
+    const float gnw = (float)P.gn_w[c0 + i], gnb = (float)P.gn_b[c0 + i], rkw = (float)P.r_k[c0 + i];
+    float shift = 0.0f;
+    if (P.shift_src && g4 == 1) shift = (float)P.shift_src[(size_t)t * D + c0 + i];
+
+    // (2) state of this thread's column slice S[16*g4 .. +15][i]: needs the batch id; requested last, consumed last
+    const uint32_t batch = P.batch1 ? P.batch1 - 1 : (P.cursors[t] & 0xffu);
     float* st = P.state + ((size_t)batch * (S + 2) + 1) * D + c0 + i;
     float Sreg[16];
 #pragma unroll
     for (int jj = 0; jj < 16; ++jj) Sreg[jj] = st[(size_t)(g4 * 16 + jj) * D];
 
-    // LoRA up-projections for the 64 channels of this head: thread = (row = tid/4, part = tid%4)
     {
-        const uint32_t row = tid >> 2, part = tid & 3u, ch = c0 + row;
-        // per-row scalars (only lane part == 0 uses them; loading in all lanes keeps the loads uniform)
-        const float w0 = (float)P.w0[ch], a0 = (float)P.a0[ch], kkw = (float)P.k_k[ch], kaw = (float)P.k_a[ch];
-        const float kraw = (float)P.k[(size_t)t * D + ch], rraw = (float)P.r[(size_t)t * D + ch];
-        float v = (float)P.v[(size_t)t * D + ch];
-        float v0w = 0.0f, vfirst = 0.0f;
-        if (!P.layer0) { v0w = (float)P.v0[ch]; vfirst = (float)P.v_first[(size_t)t * D + ch]; }
-        const float dw = lora_row_dot<4>((const f16*)((const uint8_t*)P.w2 + (size_t)ch * P.w2_rb), P.aux_w + (size_t)t * P.rw, P.rw, part);
-        const float da = lora_row_dot<4>((const f16*)((const uint8_t*)P.a2 + (size_t)ch * P.a2_rb), P.aux_a + (size_t)t * P.ra, P.ra, part);
-        const float dg = lora_row_dot<16>((const f16*)((const uint8_t*)P.g2 + (size_t)ch * P.g2_rb), P.aux_g + (size_t)t * P.rg, P.rg, part);
+        const float dw = lora_dot<4>(lw, P.rw, part);
+        const float da = lora_dot<4>(la, P.ra, part);
+        const float dg = lora_dot<GCH>(lg, P.rg, part);
         float dv = 0.0f;
-        if (!P.layer0) dv = lora_row_dot<4>((const f16*)((const uint8_t*)P.v2 + (size_t)ch * P.v2_rb), P.aux_v + (size_t)t * P.rv, P.rv, part);
+        if (!P.layer0) dv = lora_dot<4>(lv, P.rv, part);
         if (part == 0) {
             const float w = r16(w0 + r16(dw));                                           // add(w0, w)
             const float a = r16(act_sigmoid(a0 + r16(da)));                              // add_activate(.., Sigmoid)
@@ -232,8 +253,8 @@ __global__ void __launch_bounds__(256) head_kernel(const HeadParams P) {
             sh_k[row] = r16(kraw * (1.0f + (a - 1.0f) * kaw));                           // control_k_v7
         }
     }
-    const float gnw = (float)P.gn_w[c0 + i], gnb = (float)P.gn_b[c0 + i], rkw = (float)P.r_k[c0 + i];
-    if (P.shift_src && g4 == 1) P.state[(size_t)batch * (S + 2) * D + c0 + i] = (float)P.shift_src[(size_t)t * D + c0 + i];
+    if (P.shift_src && g4 == 1) P.state[(size_t)batch * (S + 2) * D + c0 + i] = shift;
+    WRK_STAMP(P.dbg, 1);     // LoRA rows arrived, per-channel scalars in LDS
     __syncthreads();
     // kk <- l2_norm(kk) over the head; a~ = -kk, b~ = kk * a
     if (g4 == 0) {
@@ -246,6 +267,7 @@ __global__ void __launch_bounds__(256) head_kernel(const HeadParams P) {
     }
     __syncthreads();
 
+    WRK_STAMP(P.dbg, 2);
     // WKV7: thread (i, g4) owns S[16*g4 .. +15][i] in registers
     float sa = 0.0f;
 #pragma unroll
@@ -265,6 +287,7 @@ __global__ void __launch_bounds__(256) head_kernel(const HeadParams P) {
     __syncthreads();
     sh_red[g4][i] = y;
     __syncthreads();
+    WRK_STAMP(P.dbg, 3);     // state updated and stored
     if (g4 == 0) {
         y = r16((sh_red[0][i] + sh_red[1][i]) + (sh_red[2][i] + sh_red[3][i]));          // att_x <- y (f16 store)
         // group norm over the head (layer_norm.wgsl GROUP_NORM)
@@ -279,6 +302,7 @@ __global__ void __launch_bounds__(256) head_kernel(const HeadParams P) {
         o = sh_g[i] * o;
         P.out[(size_t)t * D + c0 + i] = (f16)o;
     }
+    WRK_STAMP(P.dbg, 4);
 }
 
 // ------------------------------------------------------------------ greedy sampling, stage 2
@@ -324,6 +348,49 @@ void argmax_finish(hipStream_t s, const float* pv, const uint32_t* pi, uint32_t 
 }
 
 }  // namespace wrk
+
+// ------------------------------------------------------------------ debug: in-kernel timeline of one layer (WRK_TIMING=1)
+static constexpr uint32_t TIMED_LAYER = 5;
+namespace {
+struct TimingState {
+    unsigned long long* dev = nullptr;
+    std::vector<std::string> labels;
+    bool enabled = false, init = false;
+} g_timing;
+}
+unsigned long long* wrk::timing_slot(wrk_ctx* ctx, const char* label) {
+    if (!g_timing.init) { const char* e = getenv("WRK_TIMING"); g_timing.enabled = e && e[0] == '1'; g_timing.init = true; }
+    if (!g_timing.enabled) return nullptr;
+    if (!g_timing.dev) {        // first call comes from wrk_v7_generate_greedy BEFORE any stream capture (label == nullptr)
+        if (hipMalloc((void**)&g_timing.dev, 64 * 16 * 8) != hipSuccess) return nullptr;
+        hipMemset(g_timing.dev, 0, 64 * 16 * 8);
+    }
+    if (!label) return nullptr;
+    for (size_t i = 0; i < g_timing.labels.size(); ++i)
+        if (g_timing.labels[i] == label) return g_timing.dev + i * 16;
+    if (g_timing.labels.size() >= 64) return nullptr;
+    g_timing.labels.push_back(label);
+    return g_timing.dev + (g_timing.labels.size() - 1) * 16;
+}
+void wrk::timing_report(wrk_ctx* ctx) {
+    if (!g_timing.enabled || !g_timing.dev || g_timing.labels.empty()) return;
+    std::vector<unsigned long long> h(64 * 16);
+    hipMemcpy(h.data(), g_timing.dev, h.size() * 8, hipMemcpyDeviceToHost);
+    unsigned long long t0 = ~0ull;
+    for (size_t i = 0; i < g_timing.labels.size() * 16; ++i) if (h[i] && h[i] < t0) t0 = h[i];
+    fprintf(stderr, "[WRK_TIMING] layer %u of the last decode step; ns since the first stamp (100 MHz clock); first WG | last WG\n", TIMED_LAYER);
+    for (size_t i = 0; i < g_timing.labels.size(); ++i) {
+        fprintf(stderr, "  %-40s", g_timing.labels[i].c_str());
+        for (int w = 0; w < 2; ++w) {
+            for (int k = 0; k < 5; ++k) {
+                const unsigned long long v = h[i * 16 + w * 8 + k];
+                if (v) fprintf(stderr, " %6llu", (v - t0) * 10); else fprintf(stderr, "      -");
+            }
+            if (w == 0) fprintf(stderr, "  |");
+        }
+        fprintf(stderr, "\n");
+    }
+}
 
 // ------------------------------------------------------------------ host: enqueue one fused decode step
 void wrk_v7_model::drop_graphs() {
@@ -394,16 +461,22 @@ int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_
     for (uint32_t li = 0; li < d.num_layer; ++li) {
         const wrk_v7_layer_desc& L = layers[li];
         float* lst = st->layer_ptr(li);
-        // batch-1 decode can fold LN + token shift into the matvec's input load (5 launches per layer instead of 7).
-        // Measured on MI355X (round 1): SLOWER than the separate LN kernel (1.14 vs 0.905 ms/token) because every wave
-        // pays three dependent L2 round trips before its first dot product; kept behind WRK_FUSE_LN=1 for experiments.
-        static const bool fuse_ln = [] { const char* e = getenv("WRK_FUSE_LN"); return e && e[0] == '1'; }();
-        bool single = fuse_ln && (T == 1);
-        if (single) {       // the fused prologue exists only in the single-kind (+F16) register kernels
-            uint32_t kinds = 0;
-            const wrk_matrix* ms[] = {L.w_r, L.w_k, L.w_v};
-            for (const wrk_matrix* m : ms) if (m->kind != WRK_MAT_F16) kinds |= 1u << (m->kind & 31);
-            if (__builtin_popcount(kinds) > 1 || L.w_r->flags != L.w_k->flags || L.w_r->flags != L.w_v->flags || D > 2048 * 4) single = false;
+        // batch-1 decode folds LN + token shift into the prologue of the matvec that consumes them (5 launches per layer
+        // instead of 7; 0.865 vs 0.963 ms/token on MI355X, round 1).  The prologue lives in the register-input kernels
+        // only: a dry run of the three launches decides per layer; WRK_FUSE_LN=0 forces the 7-launch path.
+        static const bool fuse_ln = [] { const char* e = getenv("WRK_FUSE_LN"); return !(e && e[0] == '0'); }();
+        bool single = fuse_ln && (T == 1) && D <= 4096;
+        if (single) {
+            MatJob k1[7] = {job(L.w_r, vec(s.x), vec(s.r), 0), job(L.w_k, vec(s.x), vec(s.k), 0), job(L.w_v, vec(s.x), vec(s.v), 0),
+                            job(L.w1, vec(s.x), vec(s.aux_w, d.lora_w), 0), job(L.a1, vec(s.x), vec(s.aux_a, d.lora_a), 0),
+                            job(L.g1, vec(s.x), vec(s.aux_g, d.lora_g), 0), job(li ? L.v1 : L.a1, vec(s.x), vec(s.aux_v, d.lora_v), 0)};
+            for (MatJob& j : k1) j.pro = 1;
+            MatJob k5 = job(L.ffn_w_k, vec(s.x), vec(s.ffn_k, F), 0);
+            k5.pro = 1;
+            MatJob k6 = job(L.ffn_w_v, vec(s.ffn_k, F), vec(s.x), 0);
+            k6.carry_dst = (float*)s.x;     // any non-null pointer: classification only
+            single = matvec(q, k1, li ? 7 : 6, ctx->num_cu, true) == 0 && matvec(q, &k5, 1, ctx->num_cu, true) == 0 &&
+                     matvec(q, &k6, 1, ctx->num_cu, true) == 0;
         }
         uint32_t batch0 = 0;
         if (single) batch0 = cursor0_batch;
@@ -434,6 +507,7 @@ int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_
                 }
                 jobs[0].ln_out = s.ln_tmp;      // LN(x): becomes the att shift state in K2
             }
+            if (li == TIMED_LAYER) jobs[0].dbg = jobs[(li ? 7 : 6) - 1].dbg = wrk::timing_slot(ctx, "K1 r,k,v + LoRA-1 (LN1 prologue)");
             const int rc = run_jobs(jobs, li ? 7 : 6);
             if (rc != 0) return wrk_fail(ctx, WRK_E_ARG, "fused K1 rejected (%d)", rc);
         }
@@ -452,11 +526,15 @@ int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_
             P.v_first = (f16*)s.att_v0; P.out = (f16*)s.att_x;
             P.state = lst; P.cursors = s.cursors; P.gn_eps = 64.0e-5f; P.l2_eps = 1.0e-12f;
             P.shift_src = single ? (const f16*)s.ln_tmp : nullptr;     // fused K0: the state carry happens here
-            head_kernel<<<dim3(H, T), 256, 0, q>>>(P);
+            P.batch1 = single ? batch0 + 1 : 0;
+            P.dbg = li == TIMED_LAYER ? wrk::timing_slot(ctx, "K2 head: LoRA-2 + WKV7 + group norm") : nullptr;
+            if (d.lora_g <= 256) head_kernel<8><<<dim3(H, T), 256, 0, q>>>(P);
+            else head_kernel<16><<<dim3(H, T), 256, 0, q>>>(P);
         }
         {   // K3: x += W_o . att_x
             MatJob j = job(L.w_o, vec(s.att_x), vec(s.x), WRK_ACT_NONE);
             j.has_res = 1; j.res = vec(s.x);
+            if (li == TIMED_LAYER) j.dbg = wrk::timing_slot(ctx, "K3 w_o + residual");
             if (run_jobs(&j, 1) != 0) return wrk_fail(ctx, WRK_E_ARG, "fused K3 rejected");
         }
         float* rowf = lst + ((size_t)batch0 * (S + 2) + (S + 1)) * D;          // ffn shift state of the sequence
@@ -474,12 +552,14 @@ int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_
                 j.pro = 1; j.pro_eps = 1.0e-5f; j.ln_w = L.ln2_w->ptr; j.ln_b = L.ln2_b->ptr; j.mixw = L.ffn_x_k->ptr; j.prev = rowf;
                 j.ln_out = s.ffn_x;             // LN(x): becomes the ffn shift state in K6's epilogue
             }
+            if (li == TIMED_LAYER) j.dbg = wrk::timing_slot(ctx, "K5 ffn key (LN2 prologue)");
             if (run_jobs(&j, 1) != 0) return wrk_fail(ctx, WRK_E_ARG, "fused K5 rejected");
         }
         {   // K6: x += W_v . relu(k)^2
             MatJob j = job(L.ffn_w_v, vec(s.ffn_k, F), vec(s.x), WRK_ACT_NONE);
             j.has_res = 1; j.res = vec(s.x);
             if (single) { j.carry_src = s.ffn_x; j.carry_dst = rowf; }
+            if (li == TIMED_LAYER) j.dbg = wrk::timing_slot(ctx, "K6 ffn value + residual");
             if (run_jobs(&j, 1) != 0) return wrk_fail(ctx, WRK_E_ARG, "fused K6 rejected");
         }
         if ((li + 1) % d.rescale == 0) wrk::affine(q, vec(s.x), 0.5f, 0.0f);
