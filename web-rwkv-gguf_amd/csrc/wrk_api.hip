@@ -396,17 +396,7 @@ int32_t wrk_op_matmul(wrk_ctx* ctx, const wrk_matrix* mat, const wrk_tensor* inp
                   make_dtensor(input), make_dtensor(output), act, (uint32_t)sparse};
     int rc = -2;
     const size_t ntok = (size_t)input->view.shape[1] * input->view.shape[2];
-    if (turbo && ntok >= 16) {
-        const size_t need = ntok * (mat->k / 32 + 1);
-        if (need > ctx->xsum_cap && !ctx->capturing) {      // grow the GEMM scratch (never while capturing)
-            WRK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            if (ctx->xsum) hipFree(ctx->xsum);
-            ctx->xsum = nullptr; ctx->xsum_cap = 0;
-            WRK_HIP(ctx, hipMalloc((void**)&ctx->xsum, need * 4));
-            ctx->xsum_cap = need;
-        }
-        rc = wrk::matmul_mfma(ctx->stream, j, ctx->num_cu, ctx->xsum, ctx->xsum_cap);
-    }
+    if (turbo && ntok >= 16) rc = wrk::matmul_mfma(ctx->stream, j, ctx->num_cu);
     if (rc == -2) rc = wrk::matvec(ctx->stream, &j, 1, ctx->num_cu);
     WRK_ARG(ctx, rc == 0, "matmul: launch configuration rejected");
     WRK_LAUNCH_CHECK(ctx);

@@ -96,9 +96,16 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     return t;
 }
 
-// debug timing (WRK_TIMING=1): thread 0 of the first / last workgroup stamps the 100 MHz wall clock
+// debug timing: thread 0 of the first / last workgroup stamps the 100 MHz wall clock.  Compiled in only by
+// `make TIMING=1` (the sched barriers that pin a stamp also constrain the production schedule); run with WRK_TIMING=1.
+#ifdef WRK_TIMING_BUILD
 #define WRK_STAMP(p, k)                                                                                       \
     do {                                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);      /* keep the stamp where it is written */                     \
         if ((p) && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))                      \
             (p)[(blockIdx.x ? 8 : 0) + (k)] = wall_clock64();                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
     } while (0)
+#else
+#define WRK_STAMP(p, k) do { } while (0)
+#endif

@@ -10,7 +10,9 @@
 // fragment, C/D = 16 rows x 16 tokens in f32.  The weights stay EXACT (ggml-canonical, f32-equivalent) although
 // the MFMA operands are f16, by feeding the matrix core small integers and applying the floating scales in f32:
 //   Q4_K / Q5_K : A = q * sc        (q <= 31, sc <= 63  ->  <= 1953 < 2048: exact in f16), one 32-k step = one
-//                 sub-block; per 256-block epilogue  total += d * acc - sum_s (dmin * m_s) * sum_x(s, token)
+//                 sub-block; the min term rides the matrix core too: a second MFMA per step with A = m_s (the 6-bit
+//                 min, splat over the fragment) accumulates m_s * sum_k x_k, so per 256-block
+//                 total += d * acc - dmin * acc_min   (no input-sum pre-pass, no LDS staging of scales)
 //   Q8_0        : A = int8 code, one step = one block; per step  total += d * acc
 //   Q6_K        : A = (q6 - 32) * sc with sc = 2*s1 + s0 split over two MFMAs (2*c*s1 even <= 4096 and c*s0 are
 //                 exact); the 16-element scale groups sit inside the fragment; per 256-block  total += d * acc
@@ -21,8 +23,12 @@
 // wrk_matvec.hip); one v_pk_mul_f16 per pair both applies the integer sub-scale and moves them to normal range.
 //
 // Work split: a workgroup owns 16 rows x (16*NT) tokens; its 4 waves split K (every 4th block / step) and their
-// partial tiles meet in LDS; grid = (M/16, N/(16*NT)).
+// partial tiles meet in LDS; grid = (sum_jobs M_j/16, N/(16*NT)): several matrices that multiply the same number of
+// tokens (r, k, v and the LoRA down-projections of a layer) run in ONE launch.  K4 blocks are software-pipelined:
+// all loads of the next 256-block (weights, scales, B fragments) are in flight while the current one is multiplied.
 // Lane l: A row = l & 15, k-group g = l >> 4 (8 consecutive k); C column (token) = l & 15, rows 4g..4g+3.
+#include <cstdlib>
+
 #include "wrk_device.h"
 
 namespace wrk {
@@ -60,44 +66,25 @@ struct GemmParams {
     uint32_t kind, k, m, row_bytes, act;
     uint32_t n;                 // tokens
     uint32_t has_res;
+    uint32_t wg_begin;          // first workgroup (in x) of this job
     DTensor in, out, res;       // [K, T, B], [M, T, B]
-    const float* xsum;          // [N][K/32] sums of 32 consecutive inputs (K4 kinds only)
+};
+
+constexpr int GEMM_MAX_JOBS = 8;
+struct GemmBatch {
+    GemmParams jobs[GEMM_MAX_JOBS];
+    int njobs;
 };
 
 // token index -> (t, b) of the [C, T, B] views
 __device__ __forceinline__ void tok_tb(const DTensor& d, uint32_t tok, uint32_t& t, uint32_t& b) { t = tok % d.shape[1]; b = tok / d.shape[1]; }
 
-// per-32 sums of the inputs: xsum[n][s] = sum_{e<32} x[n][32 s + e]
-__global__ void __launch_bounds__(256) xsum32_kernel(DTensor in, float* __restrict__ xsum, uint32_t k32) {
-    const uint32_t tok = blockIdx.y;
-    uint32_t t, b;
-    tok_tb(in, tok, t, b);
-    const size_t base = dt_index(in, 0, t, b);
-    for (uint32_t s = blockIdx.x * 256 + threadIdx.x; s < k32; s += gridDim.x * 256) {
-        float acc = 0.0f;
-        if (in.dtype == WRK_F16 && ((base & 7u) == 0)) {
-            const f16* p = (const f16*)in.p + base + (size_t)s * 32;
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const f16x8 x = *(const f16x8*)(p + v * 8);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc += (float)x[e];
-            }
-        } else {
-            for (int e = 0; e < 32; ++e) acc += (float)(f16)dt_load(in, base + (size_t)s * 32 + e);
-        }
-        xsum[(size_t)tok * k32 + s] = acc;
-    }
-}
-
 template <int KIND, int NT>
-__global__ void __launch_bounds__(256) gemm_kernel(const GemmParams P) {
-    __shared__ float sh_scale[4][16][12];       // per wave: [row][d, mn0..mn7] staged by the row lanes (K4 kinds)
-    __shared__ float sh_tot[3][NT][4][64];      // K-split partial sums of waves 1..3
+__device__ __forceinline__ void gemm_body(const GemmParams& P, float (*sh_tot)[NT][4][64]) {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t r = lane & 15, g = lane >> 4;
     // a workgroup owns 16 rows; its 4 waves split K (wave w takes every 4th block / step) and meet in LDS
-    const uint32_t m0 = blockIdx.x * 16;
+    const uint32_t m0 = (blockIdx.x - P.wg_begin) * 16;
     const uint32_t row = min(m0 + r, P.m - 1);
     const uint8_t* wrow = P.w + (size_t)row * P.row_bytes;
     const uint32_t n0 = blockIdx.y * 16 * NT;
@@ -194,31 +181,38 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmParams P) {
     } else {   // Q4_K / Q5_K
         const uint32_t hoff = KIND == WRK_MAT_Q4_K ? nb * 128 : nb * 160;     // (d, dmin) plane
         const uint32_t soff = hoff + nb * 4;                                   // unpacked scales plane
-        const uint32_t k32 = K >> 5;
-        for (uint32_t b = wave; b < nb; b += 4) {
-            // the 16 row lanes of the wave (g == 0) stage d and dmin*m_s of their row for the C-row owners
-            const uint32_t dd16 = *(const uint32_t*)(wrow + hoff + (size_t)b * 4);
-            const u32x4 sm = *(const u32x4*)(wrow + soff + (size_t)b * 16);
-            const float d = (float)__builtin_bit_cast(f16, (uint16_t)(dd16 & 0xffffu)), dmin = (float)__builtin_bit_cast(f16, (uint16_t)(dd16 >> 16));
-            if (g == 0) {
-                float* o = sh_scale[wave][r];
-                o[0] = d * 16384.0f;                                                   // acc is in units of 2^-14
+        // everything one 256-block needs, requested together (one memory round trip per block, the next block's
+        // trip overlapping this block's MFMAs when registers allow: NT <= 2)
+        struct Blk {
+            u32x2 q[4];             // quant bytes of this lane's 8 k per 64-element step
+            u32x2 qh;               // Q5_K high bits
+            u32x4 sm;               // (sc, sc', m, m') bytes of the row's four 64-element groups
+            uint32_t dd[4];         // (d, dmin) of the four C rows this lane owns
+            f16x8 bf[NT][8];        // B fragments of the eight 32-k sub-blocks
+        };
+        const uint8_t* crow[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t v = sm[j];
-                    o[1 + 2 * j] = dmin * (float)((v >> 16) & 0xffu);
-                    o[2 + 2 * j] = dmin * (float)(v >> 24);
-                }
-            }
-            u32x2 qh = {0u, 0u};
-            if (KIND == WRK_MAT_Q5_K) qh = *(const u32x2*)(wrow + (size_t)nb * 128 + (size_t)b * 32 + 8 * g);
-            f32x4v acc[NT];
+        for (int i = 0; i < 4; ++i) crow[i] = P.w + (size_t)min(m0 + 4 * g + i, P.m - 1) * P.row_bytes + hoff;
+        auto load_blk = [&](Blk& R, uint32_t b) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < 4; ++j) R.q[j] = *(const u32x2*)(wrow + (size_t)b * 128 + j * 32 + 8 * g);
+            if (KIND == WRK_MAT_Q5_K) R.qh = *(const u32x2*)(wrow + (size_t)nb * 128 + (size_t)b * 32 + 8 * g);
+            R.sm = *(const u32x4*)(wrow + soff + (size_t)b * 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) R.dd[i] = *(const uint32_t*)(crow[i] + (size_t)b * 4);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int sb = 0; sb < 8; ++sb) R.bf[t][sb] = loadB(t, b * 256 + sb * 32);
+        };
+        auto mul_blk = [&](const Blk& R) {
+            f32x4v acc[NT], amin[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { acc[t] = (f32x4v){0.f, 0.f, 0.f, 0.f}; amin[t] = (f32x4v){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const u32x2 q = *(const u32x2*)(wrow + (size_t)b * 128 + j * 32 + 8 * g);
-                const uint32_t v = sm[j];
+                const u32x2 q = R.q[j];
+                const uint32_t v = R.sm[j];
                 const float sc0 = (float)(v & 0xffu), sc1 = (float)((v >> 8) & 0xffu);
                 f16x8 alo, ahi;
                 if (KIND == WRK_MAT_Q4_K) {
@@ -226,40 +220,44 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmParams P) {
                     ahi = mul8(codes8(q.x & 0xf0f0f0f0u, q.y & 0xf0f0f0f0u), sc1 * 64.0f);            // (16q)*sc*2^-18
                 } else {
                     const uint32_t s0 = 2 * j, s1 = 2 * j + 1;
-                    alo = mul8(codes8((q.x & 0x0f0f0f0fu) | (((qh.x >> s0) & 0x01010101u) << 4), (q.y & 0x0f0f0f0fu) | (((qh.y >> s0) & 0x01010101u) << 4)), sc0 * 1024.0f);
-                    ahi = mul8(codes8(((q.x >> 4) & 0x0f0f0f0fu) | (((qh.x >> s1) & 0x01010101u) << 4), ((q.y >> 4) & 0x0f0f0f0fu) | (((qh.y >> s1) & 0x01010101u) << 4)), sc1 * 1024.0f);
+                    alo = mul8(codes8((q.x & 0x0f0f0f0fu) | (((R.qh.x >> s0) & 0x01010101u) << 4), (q.y & 0x0f0f0f0fu) | (((R.qh.y >> s0) & 0x01010101u) << 4)), sc0 * 1024.0f);
+                    ahi = mul8(codes8(((q.x >> 4) & 0x0f0f0f0fu) | (((R.qh.x >> s1) & 0x01010101u) << 4), ((q.y >> 4) & 0x0f0f0f0fu) | (((R.qh.y >> s1) & 0x01010101u) << 4)), sc1 * 1024.0f);
                 }
-                const uint32_t koff = b * 256 + j * 64;
+                // min term on the matrix core: A = m (integer <= 63, exact), so acc_min = m * sum_k x_k in f32
+                const f16 m0h = (f16)(float)((v >> 16) & 0xffu), m1h = (f16)(float)(v >> 24);
+                const f16x8 mlo = {m0h, m0h, m0h, m0h, m0h, m0h, m0h, m0h}, mhi = {m1h, m1h, m1h, m1h, m1h, m1h, m1h, m1h};
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    acc[t] = mfma16(alo, loadB(t, koff), acc[t]);
-                    acc[t] = mfma16(ahi, loadB(t, koff + 32), acc[t]);
+                    acc[t] = mfma16(alo, R.bf[t][2 * j], acc[t]);
+                    acc[t] = mfma16(ahi, R.bf[t][2 * j + 1], acc[t]);
+                    amin[t] = mfma16(mlo, R.bf[t][2 * j], amin[t]);
+                    amin[t] = mfma16(mhi, R.bf[t][2 * j + 1], amin[t]);
                 }
             }
-            // epilogue of the block: rows 4g..4g+3, token column r
-            __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the LDS stores of this wave have landed (same wave, in order)
-            __builtin_amdgcn_wave_barrier();
+            // block epilogue for C rows 4g..4g+3: total += d * acc * 2^14 - dmin * acc_min
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const uint32_t tok = n0 + 16 * t + r;
-                float xs[8];
-                if (tok < P.n) {
-                    const f32x4 x0 = *(const f32x4*)(P.xsum + (size_t)tok * k32 + b * 8), x1 = *(const f32x4*)(P.xsum + (size_t)tok * k32 + b * 8 + 4);
-                    xs[0] = x0[0]; xs[1] = x0[1]; xs[2] = x0[2]; xs[3] = x0[3]; xs[4] = x1[0]; xs[5] = x1[1]; xs[6] = x1[2]; xs[7] = x1[3];
-                } else {
+            for (int i = 0; i < 4; ++i) {
+                const float d = (float)__builtin_bit_cast(f16, (uint16_t)(R.dd[i] & 0xffffu)) * 16384.0f;
+                const float dmin = (float)__builtin_bit_cast(f16, (uint16_t)(R.dd[i] >> 16));
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) xs[e] = 0.0f;
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float* o = sh_scale[wave][4 * g + i];
-                    float mins = 0.0f;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) mins = __builtin_fmaf(o[1 + e], xs[e], mins);
-                    total[t][i] += o[0] * acc[t][i] - mins;
-                }
+                for (int t = 0; t < NT; ++t) total[t][i] += d * acc[t][i] - dmin * amin[t][i];
             }
-            __builtin_amdgcn_wave_barrier();
+        };
+        if (NT <= 2) {
+            Blk cur, nxt;
+            if (wave < nb) load_blk(cur, wave);
+            for (uint32_t b = wave; b < nb; b += 4) {
+                const bool more = b + 4 < nb;
+                if (more) load_blk(nxt, b + 4);
+                mul_blk(cur);
+                if (more) cur = nxt;
+            }
+        } else {
+            Blk cur;
+            for (uint32_t b = wave; b < nb; b += 4) {
+                load_blk(cur, b);
+                mul_blk(cur);
+            }
         }
     }
 
@@ -295,41 +293,66 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmParams P) {
     }
 }
 
-template <int KIND>
-static void launch_gemm(hipStream_t s, const GemmParams& P) {
-    const uint32_t gx = (P.m + 15) / 16;
-    // tokens per wave: enough tiles to amortise the decode, few enough to keep >= ~2 waves per SIMD
-    if (P.n > 64) gemm_kernel<KIND, 4><<<dim3(gx, (P.n + 63) / 64), 256, 0, s>>>(P);
-    else if (P.n > 16) gemm_kernel<KIND, 2><<<dim3(gx, (P.n + 31) / 32), 256, 0, s>>>(P);
-    else gemm_kernel<KIND, 1><<<dim3(gx, (P.n + 15) / 16), 256, 0, s>>>(P);
-}
-
-// returns -2 when this job is not for the MFMA path (caller falls back to the matvec kernels)
-int matmul_mfma(hipStream_t s, const MatJob& j, int, float* xsum_scratch, size_t xsum_cap) {
-    const uint32_t n = j.in.shape[1] * j.in.shape[2];
-    if (n < 16) return -2;
-    if (j.flags & WRK_MATRIX_ROUND_F16) return -2;          // parity mode: per-element f16 rounding lives in the matvec kernels
-    if (j.in.dtype != WRK_F16 || (j.k & 31u)) return -2;
-    // rows of the input views must be 16-byte aligned for the B-fragment loads
-    if ((j.in.stride[0] & 7u) || (j.in.offset[0] & 7u)) return -2;
-    GemmParams P;
-    P.w = j.w; P.kind = j.kind; P.k = j.k; P.m = j.m; P.row_bytes = j.row_bytes; P.act = j.act; P.n = n;
-    P.has_res = j.has_res; P.in = j.in; P.out = j.out; P.res = j.res; P.xsum = nullptr;
-    switch (j.kind) {
-        case WRK_MAT_F16: launch_gemm<WRK_MAT_F16>(s, P); return 0;
-        case WRK_MAT_Q8_0: launch_gemm<WRK_MAT_Q8_0>(s, P); return 0;
-        case WRK_MAT_Q6_K: launch_gemm<WRK_MAT_Q6_K>(s, P); return 0;
-        case WRK_MAT_Q4_K:
-        case WRK_MAT_Q5_K: {
-            const uint32_t k32 = j.k >> 5;
-            if (!xsum_scratch || (size_t)n * k32 > xsum_cap) return -2;
-            xsum32_kernel<<<dim3((k32 + 255) / 256, n), 256, 0, s>>>(j.in, xsum_scratch, k32);
-            P.xsum = xsum_scratch;
-            if (j.kind == WRK_MAT_Q4_K) launch_gemm<WRK_MAT_Q4_K>(s, P); else launch_gemm<WRK_MAT_Q5_K>(s, P);
-            return 0;
-        }
-        default: return -2;
+// One launch, several matrices: blockIdx.x -> job (like the matvec launches), kind dispatched at run time.
+template <int NT>
+__global__ void __launch_bounds__(256) gemm_kernel(const GemmBatch B) {
+    __shared__ float sh_tot[3][NT][4][64];      // K-split partial sums of waves 1..3
+    int ji = 0;
+#pragma unroll
+    for (int q = 1; q < GEMM_MAX_JOBS; ++q)
+        if (q < B.njobs && blockIdx.x >= B.jobs[q].wg_begin) ji = q;
+    const GemmParams& P = B.jobs[ji];
+    switch (P.kind) {
+        case WRK_MAT_Q4_K: gemm_body<WRK_MAT_Q4_K, NT>(P, sh_tot); break;
+        case WRK_MAT_Q5_K: gemm_body<WRK_MAT_Q5_K, NT>(P, sh_tot); break;
+        case WRK_MAT_Q6_K: gemm_body<WRK_MAT_Q6_K, NT>(P, sh_tot); break;
+        case WRK_MAT_Q8_0: gemm_body<WRK_MAT_Q8_0, NT>(P, sh_tot); break;
+        default: gemm_body<WRK_MAT_F16, NT>(P, sh_tot); break;
     }
 }
+
+// fewest stacked tokens sent to the matrix cores (tiles are padded to 16 tokens; below this the matvec kernels run)
+uint32_t gemm_min_tokens() {
+    static const uint32_t v = [] { const char* e = getenv("WRK_GEMM_MIN"); const int x = e ? atoi(e) : 4; return (uint32_t)(x < 2 ? 2 : x); }();     // measured: B=4 break-even, B=8 2x in favour of MFMA
+    return v;
+}
+
+static bool gemm_ok(const MatJob& j, uint32_t n) {
+    if (j.in.shape[1] * j.in.shape[2] != n || n < gemm_min_tokens()) return false;
+    if (j.flags & WRK_MATRIX_ROUND_F16) return false;       // parity mode: per-element f16 rounding lives in the matvec kernels
+    if (j.in.dtype != WRK_F16 || (j.k & 31u)) return false;
+    // rows of the input views must be 16-byte aligned for the B-fragment loads
+    if ((j.in.stride[0] & 7u) || (j.in.offset[0] & 7u)) return false;
+    switch (j.kind) {
+        case WRK_MAT_F16: case WRK_MAT_Q8_0: case WRK_MAT_Q6_K: case WRK_MAT_Q4_K: case WRK_MAT_Q5_K: return true;
+        default: return false;
+    }
+}
+
+// All jobs multiply the same number of tokens; they run in ONE launch.  Returns -2 when any job is not for the MFMA
+// path (n < 16, ROUND_F16, non-f16 / unaligned input, K % 32, Int8 / NF4): the caller falls back to the matvec kernels.
+int matmul_mfma_multi(hipStream_t s, const MatJob* jobs, int njobs, int) {
+    if (njobs <= 0 || njobs > GEMM_MAX_JOBS) return -2;
+    const uint32_t n = jobs[0].in.shape[1] * jobs[0].in.shape[2];
+    for (int j = 0; j < njobs; ++j)
+        if (!gemm_ok(jobs[j], n)) return -2;
+    GemmBatch B;
+    B.njobs = njobs;
+    uint32_t wg = 0;
+    for (int q = 0; q < njobs; ++q) {
+        const MatJob& j = jobs[q];
+        GemmParams& P = B.jobs[q];
+        P.w = j.w; P.kind = j.kind; P.k = j.k; P.m = j.m; P.row_bytes = j.row_bytes; P.act = j.act; P.n = n;
+        P.has_res = j.has_res; P.in = j.in; P.out = j.out; P.res = j.res; P.wg_begin = wg;
+        wg += (j.m + 15) / 16;
+    }
+    // tokens per wave: enough tiles to amortise the decode, few enough to keep >= ~2 waves per SIMD
+    if (n > 64) gemm_kernel<4><<<dim3(wg, (n + 63) / 64), 256, 0, s>>>(B);
+    else if (n > 16) gemm_kernel<2><<<dim3(wg, (n + 31) / 32), 256, 0, s>>>(B);
+    else gemm_kernel<1><<<dim3(wg, (n + 15) / 16), 256, 0, s>>>(B);
+    return 0;
+}
+
+int matmul_mfma(hipStream_t s, const MatJob& j, int num_cu, float*, size_t) { return matmul_mfma_multi(s, &j, 1, num_cu); }
 
 }  // namespace wrk

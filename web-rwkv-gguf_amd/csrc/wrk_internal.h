@@ -180,7 +180,10 @@ uint32_t matvec_num_wg(const MatJob* jobs, int njobs, int num_cu, uint32_t* rows
 int matvec(hipStream_t s, const MatJob* jobs, int njobs, int num_cu, bool dry_run = false);
 // MFMA dequant-GEMM (wrk_gemm.hip); -2 = not applicable (caller uses the matvec kernels).  xsum_scratch: device
 // f32 buffer of at least tokens * K/32 elements (only the K4 kinds use it)
-int matmul_mfma(hipStream_t s, const MatJob& job, int num_cu, float* xsum_scratch, size_t xsum_cap);
+int matmul_mfma(hipStream_t s, const MatJob& job, int num_cu, float* unused = nullptr, size_t unused_cap = 0);
+// several matrices x the same tokens in ONE launch (-2 if any job is not for the MFMA path)
+int matmul_mfma_multi(hipStream_t s, const MatJob* jobs, int njobs, int num_cu);
+uint32_t gemm_min_tokens();
 // wrk_quant.hip
 void quantize_int8(hipStream_t s, const void* src_f16, uint8_t* dst, uint32_t k, uint32_t m, uint32_t row_bytes);
 void quantize_nf4(hipStream_t s, const void* src_f16, const float* levels, uint8_t* dst, uint32_t k, uint32_t m, uint32_t row_bytes);

@@ -452,6 +452,8 @@ __device__ __forceinline__ float sum8(f16x8 a) {
     return s;
 }
 
+// only REQUEST the input vectors of chunk c (sums are taken later, by x_sums, so that the weight loads can be issued
+// behind these small L2-resident loads and waited for separately: memory returns in issue order)
 template <int KIND>
 __device__ __forceinline__ XRegs load_x(const f16* __restrict__ x, uint32_t c, bool valid) {
     XRegs r;
@@ -464,9 +466,13 @@ __device__ __forceinline__ XRegs load_x(const f16* __restrict__ x, uint32_t c, b
     r.v[0] = *(const f16x8*)(x + lo);
     if (KIND != WRK_MAT_F16) r.v[1] = *(const f16x8*)(x + lo + 8);
     if (KIND != WRK_MAT_F16 && KIND != WRK_MAT_Q8_0) { r.v[2] = *(const f16x8*)(x + hi); r.v[3] = *(const f16x8*)(x + hi + 8); }
+    return r;
+}
+
+template <int KIND>
+__device__ __forceinline__ void x_sums(XRegs& r) {
     if (KIND != WRK_MAT_F16) r.s[0] = sum8(r.v[0]) + sum8(r.v[1]);
     if (KIND != WRK_MAT_F16 && KIND != WRK_MAT_Q8_0) r.s[1] = sum8(r.v[2]) + sum8(r.v[3]);
-    return r;
 }
 
 __device__ __forceinline__ float dot16r(const f16x2 (&q)[8], const f16x8 xa, const f16x8 xb) {
@@ -670,9 +676,20 @@ __device__ __forceinline__ void matvec_body_reg(const JobDev& J, unsigned char* 
             }
     };
     WRK_STAMP(J.dbg, 0);
-    issue(0);       // weights first: they do not depend on the activations
+    // Issue order = return order: the small L2-resident operands (input row, LN vectors, residuals) go out FIRST and
+    // the weight rows right behind them, so the prologue / input sums run while the weight burst is still arriving
+    // and the first row's dot product can start as soon as that row is in (WRK_TIMING: weights-first cost ~1 us).
     const f16* xin = (const f16*)J.in.p + dt_index(J.in, 0, 0, 0);
     XRegs x[XI];
+    float res_pre[RB], carry_pre[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        res_pre[rb] = carry_pre[rb] = 0.0f;
+        const uint32_t r = KS == 1 ? row_of(rb) : r0 + tid;
+        const bool mine = KS == 1 ? (uint32_t)rb < nrows : (rb == 0 && tid < nrows);
+        if (mine && J.has_res) res_pre[rb] = dt_load(J.res, dt_index(J.res, r, 0, 0));
+        if (mine && J.carry_dst) carry_pre[rb] = (float)J.carry_src[r];
+    }
     if (J.pro) {
         // Fused layer_norm + token_shift prologue, computed ONCE per workgroup: thread t owns elements 8t..8t+7 (and
         // +2048), every global vector (row, LN weight/bias, shift state, mix factor) is requested up front, the two
@@ -695,9 +712,10 @@ __device__ __forceinline__ void matvec_body_reg(const JobDev& J, unsigned char* 
                 pv[v][1] = *(const f32x4*)(J.prev + i * 8 + 4);
             }
         }
+        const float c0 = (float)xin[0];
+        issue(0);
         // one pass, one block reduction: sums of (x - c) and (x - c)^2 around c = x[0] (any constant is exact in
         // infinite precision; a value of the row keeps the cancellation of E[d^2] - E[d]^2 harmless)
-        const float c0 = (float)xin[0];
         float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
         for (int v = 0; v < VPT; ++v)
@@ -710,6 +728,7 @@ __device__ __forceinline__ void matvec_body_reg(const JobDev& J, unsigned char* 
         __syncthreads();
         s1 = (red[0] + red[1]) + (red[2] + red[3]);
         s2 = (red[4] + red[5]) + (red[6] + red[7]);
+        WRK_STAMP(J.dbg, 4);                    // row arrived, statistics reduced
         const float md = s1 / (float)K;
         const float mean = c0 + md;
         const float dev = 1.0f / sqrtf(fmaxf(s2 / (float)K - md * md, 0.0f) + J.pro_eps);
@@ -734,23 +753,15 @@ __device__ __forceinline__ void matvec_body_reg(const JobDev& J, unsigned char* 
     } else {
 #pragma unroll
         for (int ci = 0; ci < XI; ++ci) x[ci] = load_x<KIND>(xin, cbase + 64 * ci, cbase + 64 * ci < nch);
+        issue(0);
     }
+#pragma unroll
+    for (int ci = 0; ci < XI; ++ci) x_sums<KIND>(x[ci]);
 
     WRK_STAMP(J.dbg, 1);                        // inputs (and prologue) done
     float* part = (float*)smem;                 // KS == 4: [32 rows][4 waves]
     float best_v = -3.0e38f;
     uint32_t best_i = 0xffffffffu;
-    // residual / carry operands of the rows this thread will finish: requested now, with everything else, so the
-    // epilogue does not start another memory round trip
-    float res_pre[RB], carry_pre[RB];
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb) {
-        res_pre[rb] = carry_pre[rb] = 0.0f;
-        const uint32_t r = KS == 1 ? row_of(rb) : r0 + tid;
-        const bool mine = KS == 1 ? (uint32_t)rb < nrows : (rb == 0 && tid < nrows);
-        if (mine && J.has_res) res_pre[rb] = dt_load(J.res, dt_index(J.res, r, 0, 0));
-        if (mine && J.carry_dst) carry_pre[rb] = (float)J.carry_src[r];
-    }
     auto finish = [&](uint32_t r, float v, float resv, float carryv) {    // activation, fused residual, store, running arg-max
         float o = act_apply(J.act, v);
         if (J.has_res) o = dt_round(J.out, o) + resv;
@@ -792,7 +803,7 @@ __device__ __forceinline__ void matvec_body_reg(const JobDev& J, unsigned char* 
         __syncthreads();
         if (tid < nrows) finish(r0 + tid, (part[tid * 4] + part[tid * 4 + 1]) + (part[tid * 4 + 2] + part[tid * 4 + 3]), res_pre[0], carry_pre[0]);
     }
-    WRK_STAMP(J.dbg, 3);
+    WRK_STAMP(J.dbg, 3);                        // rows reduced and stored
     if (J.amax_val) {       // fused greedy sampling, stage 1 (uniform branch: every wave of the launch takes it)
         float* sv = (float*)(smem + 512);
         uint32_t* si = (uint32_t*)(smem + 528);

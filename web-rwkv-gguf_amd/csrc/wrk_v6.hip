@@ -88,7 +88,7 @@ int32_t wrk_v6_model::ensure_history(size_t n) {
 static int32_t mm6(wrk_ctx* ctx, const wrk_matrix* m, DTensor in, DTensor out, uint32_t act) {
     wrk::MatJob j{m->data, m->aux, m->kind, m->flags, m->k, m->m, (uint32_t)m->row_bytes, in, out, act, 0};
     int rc = -2;
-    if (in.shape[1] * in.shape[2] >= 16) rc = wrk::matmul_mfma(ctx->stream, j, ctx->num_cu, ctx->xsum, ctx->xsum_cap);
+    if (in.shape[1] * in.shape[2] >= wrk::gemm_min_tokens()) rc = wrk::matmul_mfma(ctx->stream, j, ctx->num_cu);
     if (rc == -2) rc = wrk::matvec(ctx->stream, &j, 1, ctx->num_cu);
     if (rc != 0) return wrk_fail(ctx, WRK_E_ARG, "matmul launch rejected (K=%u M=%u rc=%d)", m->k, m->m, rc);
     return WRK_OK;

@@ -92,7 +92,7 @@ static wrk::MatJob mj(const wrk_matrix* m, DTensor in, DTensor out, uint32_t act
 static int32_t mm(wrk_ctx* ctx, const wrk_matrix* m, DTensor in, DTensor out, uint32_t act) {
     wrk::MatJob j = mj(m, in, out, act);
     int rc = -2;
-    if (in.shape[1] * in.shape[2] >= 16) rc = wrk::matmul_mfma(ctx->stream, j, ctx->num_cu, ctx->xsum, ctx->xsum_cap);
+    if (in.shape[1] * in.shape[2] >= wrk::gemm_min_tokens()) rc = wrk::matmul_mfma(ctx->stream, j, ctx->num_cu);
     if (rc == -2) rc = wrk::matvec(ctx->stream, &j, 1, ctx->num_cu);
     if (rc != 0) return wrk_fail(ctx, WRK_E_ARG, "matmul launch rejected (K=%u M=%u)", m->k, m->m);
     return WRK_OK;

@@ -434,9 +434,10 @@ int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_
     auto vec = [&](void* p, uint32_t c = 0) { return make_dense(p, WRK_F16, c ? c : D, T); };
     // batched decode (many sequences): each matrix goes to the MFMA GEMM; few sequences: one multi-matrix matvec launch
     auto run_jobs = [&](MatJob* jobs, int n) -> int {
-        if (T >= 9) {
+        if (T >= gemm_min_tokens()) {
+            if (matmul_mfma_multi(q, jobs, n, ctx->num_cu) == 0) return 0;      // all matrices of the stage in one launch
             for (int i = 0; i < n; ++i) {
-                int rc = matmul_mfma(q, jobs[i], ctx->num_cu, ctx->xsum, ctx->xsum_cap);
+                int rc = matmul_mfma(q, jobs[i], ctx->num_cu);
                 if (rc == -2) rc = matvec(q, &jobs[i], 1, ctx->num_cu);
                 if (rc != 0) return rc;
             }

@@ -10,12 +10,12 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-from typing import List, Optional, Sequence
+from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIBDIR = os.path.join(os.path.dirname(_HERE), "lib")
+_LIBDIR = os.environ.get("WRK_LIB_DIR") or os.path.join(os.path.dirname(_HERE), "lib")   # WRK_LIB_DIR: e.g. the `make TIMING=1` build
 LIB_HIP = os.path.join(_LIBDIR, "libwrk_hip.so")
 LIB_RT = os.path.join(_LIBDIR, "libwrk_runtime.so")
 
