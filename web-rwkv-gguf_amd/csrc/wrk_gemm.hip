@@ -181,31 +181,35 @@ __device__ __forceinline__ void gemm_body(const GemmParams& P, float (*sh_tot)[N
     } else {   // Q4_K / Q5_K
         const uint32_t hoff = KIND == WRK_MAT_Q4_K ? nb * 128 : nb * 160;     // (d, dmin) plane
         const uint32_t soff = hoff + nb * 4;                                   // unpacked scales plane
-        // everything one 256-block needs, requested together (one memory round trip per block, the next block's
-        // trip overlapping this block's MFMAs when registers allow: NT <= 2)
-        struct Blk {
+        // Loads of one 256-block.  Weights/scales (18 VGPRs) are prefetched FOUR blocks ahead and the B fragments one
+        // block ahead: a wave walks its blocks serially, so without depth every block costs a full memory round trip
+        // (rocprof round 1: 13 us for a 9 MB matrix x 16 tokens, i.e. latency, not bytes).
+        struct WBlk {
             u32x2 q[4];             // quant bytes of this lane's 8 k per 64-element step
             u32x2 qh;               // Q5_K high bits
             u32x4 sm;               // (sc, sc', m, m') bytes of the row's four 64-element groups
             uint32_t dd[4];         // (d, dmin) of the four C rows this lane owns
-            f16x8 bf[NT][8];        // B fragments of the eight 32-k sub-blocks
         };
+        struct BBlk { f16x8 bf[NT <= 2 ? NT : 1][8]; };   // B fragments of the eight 32-k sub-blocks
         const uint8_t* crow[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) crow[i] = P.w + (size_t)min(m0 + 4 * g + i, P.m - 1) * P.row_bytes + hoff;
-        auto load_blk = [&](Blk& R, uint32_t b) {
+        auto load_w = [&](WBlk& R, uint32_t b) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) R.q[j] = *(const u32x2*)(wrow + (size_t)b * 128 + j * 32 + 8 * g);
             if (KIND == WRK_MAT_Q5_K) R.qh = *(const u32x2*)(wrow + (size_t)nb * 128 + (size_t)b * 32 + 8 * g);
             R.sm = *(const u32x4*)(wrow + soff + (size_t)b * 16);
 #pragma unroll
             for (int i = 0; i < 4; ++i) R.dd[i] = *(const uint32_t*)(crow[i] + (size_t)b * 4);
+        };
+        auto load_b = [&](BBlk& R, uint32_t b) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
+            for (int t = 0; t < (NT <= 2 ? NT : 1); ++t)
 #pragma unroll
                 for (int sb = 0; sb < 8; ++sb) R.bf[t][sb] = loadB(t, b * 256 + sb * 32);
         };
-        auto mul_blk = [&](const Blk& R) {
+        // NT > 2 (prefill): B fragments are fetched per 64-k step instead (a whole block of them would be 128 VGPRs)
+        auto mul_blk = [&](const WBlk& R, const BBlk& X, uint32_t b) {
             f32x4v acc[NT], amin[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) { acc[t] = (f32x4v){0.f, 0.f, 0.f, 0.f}; amin[t] = (f32x4v){0.f, 0.f, 0.f, 0.f}; }
@@ -228,10 +232,12 @@ __device__ __forceinline__ void gemm_body(const GemmParams& P, float (*sh_tot)[N
                 const f16x8 mlo = {m0h, m0h, m0h, m0h, m0h, m0h, m0h, m0h}, mhi = {m1h, m1h, m1h, m1h, m1h, m1h, m1h, m1h};
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    acc[t] = mfma16(alo, R.bf[t][2 * j], acc[t]);
-                    acc[t] = mfma16(ahi, R.bf[t][2 * j + 1], acc[t]);
-                    amin[t] = mfma16(mlo, R.bf[t][2 * j], amin[t]);
-                    amin[t] = mfma16(mhi, R.bf[t][2 * j + 1], amin[t]);
+                    const f16x8 b0 = NT <= 2 ? X.bf[t][2 * j] : loadB(t, b * 256 + j * 64);
+                    const f16x8 b1 = NT <= 2 ? X.bf[t][2 * j + 1] : loadB(t, b * 256 + j * 64 + 32);
+                    acc[t] = mfma16(alo, b0, acc[t]);
+                    acc[t] = mfma16(ahi, b1, acc[t]);
+                    amin[t] = mfma16(mlo, b0, amin[t]);
+                    amin[t] = mfma16(mhi, b1, amin[t]);
                 }
             }
             // block epilogue for C rows 4g..4g+3: total += d * acc * 2^14 - dmin * acc_min
@@ -243,20 +249,35 @@ __device__ __forceinline__ void gemm_body(const GemmParams& P, float (*sh_tot)[N
                 for (int t = 0; t < NT; ++t) total[t][i] += d * acc[t][i] - dmin * amin[t][i];
             }
         };
+        const uint32_t nmine = wave < nb ? (nb - wave + 3) >> 2 : 0;      // blocks of this wave: wave, wave+4, ...
+        // prefetch depth by regime: few tokens = few waves per CU = latency-bound (deep); many tokens = register-bound
+        constexpr int WD = NT == 1 ? 4 : (NT == 2 ? 2 : 1);
+        WBlk W[WD];
+#pragma unroll
+        for (int u = 0; u < WD; ++u)
+            if ((uint32_t)u < nmine) load_w(W[u], wave + 4 * u);
         if (NT <= 2) {
-            Blk cur, nxt;
-            if (wave < nb) load_blk(cur, wave);
-            for (uint32_t b = wave; b < nb; b += 4) {
-                const bool more = b + 4 < nb;
-                if (more) load_blk(nxt, b + 4);
-                mul_blk(cur);
-                if (more) cur = nxt;
+            constexpr int XD = NT == 1 ? 2 : 1;     // B fragments double-buffered only in the 16-token regime
+            BBlk X[XD];
+            if (XD == 2 && nmine) load_b(X[0], wave);
+            for (uint32_t i0 = 0; i0 < nmine; i0 += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {       // unrolled by 4 so that every buffer index is a compile-time constant
+                    const uint32_t i = i0 + u;
+                    if (i >= nmine) break;
+                    const uint32_t b = wave + 4 * i;
+                    if (XD == 2) { if (i + 1 < nmine) load_b(X[(u + 1) % XD], b + 4); }
+                    else load_b(X[0], b);
+                    mul_blk(W[u % WD], X[u % XD], b);
+                    if (i + WD < nmine) load_w(W[u % WD], b + 4 * WD);
+                }
             }
         } else {
-            Blk cur;
-            for (uint32_t b = wave; b < nb; b += 4) {
-                load_blk(cur, b);
-                mul_blk(cur);
+            BBlk X;     // unused
+            for (uint32_t i = 0; i < nmine; ++i) {
+                const uint32_t b = wave + 4 * i;
+                mul_blk(W[0], X, b);
+                if (i + 1 < nmine) load_w(W[0], b + 4);
             }
         }
     }

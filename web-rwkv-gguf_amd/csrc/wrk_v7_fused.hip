@@ -574,14 +574,22 @@ int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_
         LN(P, NH);
         MatJob j = job(head, make_dense(s.head_x, WRK_F16, D, NH), make_dense(s.head_o, WRK_F32, V, NH), WRK_ACT_NONE);
         uint32_t nwg = 0;
-        if (want_argmax) {
-            nwg = matvec_num_wg(&j, 1, ctx->num_cu, nullptr);
-            if ((size_t)nwg * NH > amax_cap) return wrk_fail(ctx, WRK_E_ARG, "arg-max scratch too small");
-            j.amax_val = amax_val; j.amax_idx = amax_idx;
+        // several header rows: the head goes to the matrix cores too and the arg-max becomes its own (tiny) kernel
+        if (NH >= gemm_min_tokens() && matmul_mfma(q, j, ctx->num_cu) == 0) {
+            if (want_argmax) {
+                wrk::argmax_rows(q, (const float*)s.head_o, V, V, NH, s.argmax);
+                if (advance) wrk::advance_tokens(q, s.argmax, s.tokens, history, s.counter, NH);
+            }
+        } else {
+            if (want_argmax) {
+                nwg = matvec_num_wg(&j, 1, ctx->num_cu, nullptr);
+                if ((size_t)nwg * NH > amax_cap) return wrk_fail(ctx, WRK_E_ARG, "arg-max scratch too small");
+                j.amax_val = amax_val; j.amax_idx = amax_idx;
+            }
+            if (matvec(q, &j, 1, ctx->num_cu) != 0) return wrk_fail(ctx, WRK_E_ARG, "fused head rejected");
+            if (want_argmax)
+                argmax_finish(q, amax_val, amax_idx, nwg, NH, s.argmax, advance ? s.tokens : nullptr, history, advance ? s.counter : nullptr);
         }
-        if (matvec(q, &j, 1, ctx->num_cu) != 0) return wrk_fail(ctx, WRK_E_ARG, "fused head rejected");
-        if (want_argmax)
-            argmax_finish(q, amax_val, amax_idx, nwg, NH, s.argmax, advance ? s.tokens : nullptr, history, advance ? s.counter : nullptr);
     }
 #undef LN
     WRK_LAUNCH_CHECK(ctx);
