@@ -15,10 +15,10 @@ from __future__ import annotations
 import numpy as np
 
 QK_K = 256
-BLOCK_BYTES = {"F32": 4, "F16": 2, "Q4_0": 18, "Q8_0": 34, "Q4_K": 144, "Q5_K": 176, "Q6_K": 210}
-BLOCK_ELEMS = {"F32": 1, "F16": 1, "Q4_0": 32, "Q8_0": 32, "Q4_K": 256, "Q5_K": 256, "Q6_K": 256}
+BLOCK_BYTES = {"F32": 4, "F16": 2, "Q4_0": 18, "Q8_0": 34, "Q2_K": 84, "Q3_K": 110, "Q4_K": 144, "Q5_K": 176, "Q6_K": 210}
+BLOCK_ELEMS = {"F32": 1, "F16": 1, "Q4_0": 32, "Q8_0": 32, "Q2_K": 256, "Q3_K": 256, "Q4_K": 256, "Q5_K": 256, "Q6_K": 256}
 # gguf.rs:888-923 (GgmlType ids)
-GGML_TYPE_ID = {"F32": 0, "F16": 1, "Q4_0": 2, "Q8_0": 8, "Q4_K": 12, "Q5_K": 13, "Q6_K": 14, "BF16": 30}
+GGML_TYPE_ID = {"F32": 0, "F16": 1, "Q4_0": 2, "Q8_0": 8, "Q2_K": 10, "Q3_K": 11, "Q4_K": 12, "Q5_K": 13, "Q6_K": 14, "BF16": 30}
 GGML_TYPE_NAME = {v: k for k, v in GGML_TYPE_ID.items()}
 
 
@@ -140,9 +140,61 @@ def dequantize_q6_k(data, num_elements: int, round_f16: bool = True) -> np.ndarr
     return _finish(out, round_f16)
 
 
+def dequantize_q2_k(data, num_elements: int, round_f16: bool = True) -> np.ndarray:
+    """gguf.rs:372-423: block = [scales 16][qs 64][d f16][dmin f16] = 84 B; per 128 elements four 2-bit planes of
+    qs[32], each plane two 16-element groups with scale byte (low nibble scale, high nibble min):
+    val = d*(sc & 15)*q - dmin*(sc >> 4)."""
+    nb = num_elements // QK_K
+    blocks = _as_u8(data)[: nb * 84].reshape(nb, 84)
+    scales, qs = blocks[:, 0:16], blocks[:, 16:80]
+    d, dmin = _f16_field(blocks, 80), _f16_field(blocks, 82)
+    out = np.empty((nb, QK_K), np.float32)
+    for n in range(2):
+        for j in range(4):
+            for h in range(2):
+                is_ = n * 8 + j * 2 + h
+                sc = scales[:, is_]
+                dl = d * (sc & 0xF).astype(np.float32)
+                ml = dmin * (sc >> 4).astype(np.float32)
+                q = ((qs[:, n * 32 + h * 16: n * 32 + h * 16 + 16] >> (2 * j)) & 3).astype(np.float32)
+                out[:, n * 128 + j * 32 + h * 16: n * 128 + j * 32 + h * 16 + 16] = dl[:, None] * q - ml[:, None]
+    return _finish(out, round_f16)
+
+
+def dequantize_q3_k(data, num_elements: int, round_f16: bool = True) -> np.ndarray:
+    """gguf.rs:280-366: block = [hmask 32][qs 64][scales 12][d f16] = 110 B; 6-bit scales unpacked with the
+    llama.cpp kmask shuffle, val = d*(sc - 32)*(q2 + (hbit ? 0 : -4))."""
+    nb = num_elements // QK_K
+    blocks = _as_u8(data)[: nb * 110].reshape(nb, 110)
+    hmask, qs = blocks[:, 0:32], blocks[:, 32:96]
+    raw = np.ascontiguousarray(blocks[:, 96:108]).view("<u4").reshape(nb, 3)
+    d_all = _f16_field(blocks, 108)
+    K1, K2 = np.uint32(0x03030303), np.uint32(0x0F0F0F0F)
+    a0, a1, tmp = raw[:, 0], raw[:, 1], raw[:, 2]
+    aux = np.empty((nb, 4), np.uint32)
+    aux[:, 2] = ((a0 >> 4) & K2) | (((tmp >> 4) & K1) << 4)
+    aux[:, 3] = ((a1 >> 4) & K2) | (((tmp >> 6) & K1) << 4)
+    aux[:, 0] = (a0 & K2) | (((tmp >> 0) & K1) << 4)
+    aux[:, 1] = (a1 & K2) | (((tmp >> 2) & K1) << 4)
+    scales = np.ascontiguousarray(aux).view(np.int8).reshape(nb, 16)
+    out = np.empty((nb, QK_K), np.float32)
+    for n in range(2):
+        for j in range(4):
+            m = np.uint8(1 << (n * 4 + j))
+            for h in range(2):
+                is_ = n * 8 + j * 2 + h
+                dl = d_all * (scales[:, is_].astype(np.int32) - 32).astype(np.float32)
+                q = ((qs[:, n * 32 + h * 16: n * 32 + h * 16 + 16] >> (2 * j)) & 3).astype(np.int32)
+                hv = np.where(hmask[:, h * 16: h * 16 + 16] & m != 0, 0, -4).astype(np.int32)
+                out[:, n * 128 + j * 32 + h * 16: n * 128 + j * 32 + h * 16 + 16] = dl[:, None] * (q + hv).astype(np.float32)
+    return _finish(out, round_f16)
+
+
 DEQUANT = {
     "Q8_0": dequantize_q8_0,
     "Q4_0": dequantize_q4_0,
+    "Q2_K": dequantize_q2_k,
+    "Q3_K": dequantize_q3_k,
     "Q4_K": dequantize_q4_k,
     "Q5_K": dequantize_q5_k,
     "Q6_K": dequantize_q6_k,

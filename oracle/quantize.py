@@ -135,12 +135,73 @@ def quantize_q4_0(w: np.ndarray) -> np.ndarray:
     return out.reshape(-1)
 
 
+def quantize_q2_k(w: np.ndarray) -> np.ndarray:
+    """Fixture quantiser (not ggml's search): per 16-element group min/scale on 4-bit grids of the block's d / dmin."""
+    x = w.astype(np.float32).reshape(-1, 16, 16)                      # [nb, group, elem]; group order = decoder's `is`
+    nb = x.shape[0]
+    mn = np.minimum(x.min(axis=2), 0.0)
+    rng = x.max(axis=2) - mn
+    dmin = (np.abs(mn).max(axis=1) / 15.0).astype(np.float16).astype(np.float32)
+    d = (rng.max(axis=1) / 3.0 / 15.0).astype(np.float16).astype(np.float32)
+    dmin = np.where(dmin > 0, dmin, np.float32(1e-6)); d = np.where(d > 0, d, np.float32(1e-6))
+    m4 = np.clip(np.rint(-mn / dmin[:, None]), 0, 15).astype(np.uint8)
+    s4 = np.clip(np.rint(rng / 3.0 / d[:, None]), 1, 15).astype(np.uint8)
+    q = np.clip(np.rint((x + (dmin[:, None] * m4)[:, :, None]) / (d[:, None] * s4)[:, :, None]), 0, 3).astype(np.uint8)
+    out = np.zeros((nb, 84), np.uint8)
+    out[:, 0:16] = s4 | (m4 << 4)
+    # element (n, j, h, l) = group n*8 + j*2 + h, lives in qs[n*32 + h*16 + l] bits 2j..2j+1
+    qs = np.zeros((nb, 64), np.uint8)
+    for n in range(2):
+        for j in range(4):
+            for h in range(2):
+                qs[:, n * 32 + h * 16: n * 32 + h * 16 + 16] |= q[:, n * 8 + j * 2 + h, :] << (2 * j)
+    out[:, 16:80] = qs
+    out[:, 80:82] = _f16_bytes(d.astype(np.float16).astype(np.float32))
+    out[:, 82:84] = _f16_bytes(dmin.astype(np.float16).astype(np.float32))
+    return out.reshape(-1)
+
+
+def quantize_q3_k(w: np.ndarray) -> np.ndarray:
+    """Fixture quantiser: 3-bit signed codes in [-4, 3] with a 6-bit (sc - 32) scale per 16 elements."""
+    x = w.astype(np.float32).reshape(-1, 16, 16)
+    nb = x.shape[0]
+    amax = np.abs(x).max(axis=2)
+    d = (amax.max(axis=1) / 4.0 / 31.0).astype(np.float16).astype(np.float32)
+    d = np.where(d > 0, d, np.float32(1e-6))
+    sc = np.clip(np.rint(amax / 4.0 / d[:, None]), 1, 31).astype(np.int32)        # (stored - 32) in [1, 31]
+    q = np.clip(np.rint(x / (d[:, None] * sc)[:, :, None]), -4, 3).astype(np.int32)
+    stored = (sc + 32).astype(np.uint8)                                            # 6-bit value
+    out = np.zeros((nb, 110), np.uint8)
+    hmask = np.zeros((nb, 32), np.uint8); qs = np.zeros((nb, 64), np.uint8)
+    for n in range(2):
+        for j in range(4):
+            for h in range(2):
+                g = q[:, n * 8 + j * 2 + h, :]
+                hi = (g >= 0)                                   # hbit set <=> no -4 offset
+                lo = np.where(hi, g, g + 4).astype(np.uint8)
+                qs[:, n * 32 + h * 16: n * 32 + h * 16 + 16] |= lo << (2 * j)
+                hmask[:, h * 16: h * 16 + 16] |= hi.astype(np.uint8) << (n * 4 + j)
+    # pack the sixteen 6-bit scales: inverse of the decoder's kmask shuffle (low 4 bits in aux0/aux1 nibbles, high 2 in tmp)
+    lo4, hi2 = (stored & 0xF).astype(np.uint32), (stored >> 4).astype(np.uint32)
+    a0 = np.zeros(nb, np.uint32); a1 = np.zeros(nb, np.uint32); tmp = np.zeros(nb, np.uint32)
+    for k in range(4):
+        a0 |= (lo4[:, k] | (lo4[:, 8 + k] << 4)) << (8 * k)
+        a1 |= (lo4[:, 4 + k] | (lo4[:, 12 + k] << 4)) << (8 * k)
+        tmp |= (hi2[:, k] | (hi2[:, 4 + k] << 2) | (hi2[:, 8 + k] << 4) | (hi2[:, 12 + k] << 6)) << (8 * k)
+    out[:, 0:32] = hmask; out[:, 32:96] = qs
+    out[:, 96:108] = np.stack([a0, a1, tmp], axis=1).astype("<u4").view(np.uint8).reshape(nb, 12)
+    out[:, 108:110] = _f16_bytes(d)
+    return out.reshape(-1)
+
+
 QUANTIZE = {
     "Q4_K": quantize_q4_k,
     "Q5_K": quantize_q5_k,
     "Q6_K": quantize_q6_k,
     "Q8_0": quantize_q8_0,
     "Q4_0": quantize_q4_0,
+    "Q2_K": quantize_q2_k,
+    "Q3_K": quantize_q3_k,
     "F16": lambda w: np.ascontiguousarray(w.astype("<f2")).view(np.uint8).reshape(-1),
     "F32": lambda w: np.ascontiguousarray(w.astype("<f4")).view(np.uint8).reshape(-1),
 }

@@ -169,7 +169,10 @@ def _mat(reader: GgufReader, name: str, weights_f16: bool, quant: str = "none", 
     if weights_f16:
         return _mat16(reader, name)
     tn, raw = reader.raw_tensor(name)
-    return dq.dequantize(tn, raw, shape[0] * shape[1], round_f16=(tn == "F32")).reshape(shape[0], shape[1])
+    # only the kinds with an inline-dequant kernel keep f32-exact weights; every other type is dequantised to f16 at
+    # load exactly as the reference does (gguf.rs:1690-1720)
+    inline = tn in ("Q4_K", "Q5_K", "Q6_K", "Q8_0", "F16")
+    return dq.dequantize(tn, raw, shape[0] * shape[1], round_f16=not inline).reshape(shape[0], shape[1])
 
 
 @dataclass

@@ -132,3 +132,14 @@ def test_host_v6_info_and_tensors_match_oracle():
     for n in ("blocks.1.att.time_mix_w2", "blocks.0.att.time_first", "blocks.1.att.gate.weight", "blocks.0.ffn.time_mix_r"):
         want = oref.tensor(n)[2].astype(np.float16).astype(np.float32)
         assert np.array_equal(r.tensor_f16(n).astype(np.float32), want), n
+
+
+@pytest.mark.parametrize("kind", ["Q2_K", "Q3_K", "Q4_0"])
+def test_host_load_time_dequant_kinds(kind):
+    """Load-time-only kinds (gguf.rs:42-75, 280-423): the C++ reader's f16 output is bit-identical to the oracle's."""
+    data = synth.make_v7_gguf(synth.CONFIGS["tiny"], 3, mat=kind)
+    oref, r = ogguf.GgufReader(data), wrk.GgufReader(data)
+    for n in ("blocks.0.att.key.weight", "blocks.1.ffn.value.weight", "blocks.1.att.output.weight"):
+        got = r.tensor_f16(n)
+        _, _, want = oref.tensor(n)
+        assert np.array_equal(got.view(np.uint16), want.astype(np.float16).view(np.uint16)), (kind, n)

@@ -58,6 +58,8 @@ VARIANTS = [
     ("tiny", wrk.WEIGHTS_INLINE, {"mat": "Q5_K", "head": "Q8_0"}),
     ("tiny", wrk.WEIGHTS_INLINE, {"mat": "Q8_0", "head": "F16", "lora": "F16"}),
     ("tiny", wrk.WEIGHTS_INLINE, {"mat": "F16", "head": "F16"}),
+    ("tiny", wrk.WEIGHTS_INLINE, {"mat": "Q3_K", "head": "Q2_K"}),          # load-time-only kinds (gguf.rs:280-423)
+    ("tiny", wrk.WEIGHTS_REFERENCE, {"mat": "Q4_0", "head": "Q4_0"}),
     ("small", wrk.WEIGHTS_INLINE, {"mat_override": {"time_mix_value": "Q6_K", "channel_mix_value": "Q6_K"}}),
 ]
 

@@ -170,3 +170,46 @@ def test_synth_is_bit_stable():
     data = synth.make_v7_gguf(synth.CONFIGS["tiny"], 42)
     # pinned when the fixture generator was written; a change means fixtures must be regenerated
     assert hashlib.sha256(data).hexdigest() == open(__file__.replace("test_oracle_gguf.py", "golden/tiny_q4k.sha256")).read().strip()
+
+
+def test_q2_k_known_answer():
+    """Hand-built Q2_K block (gguf.rs:372-423): scales byte 0x21 -> scale 1, min 2; d = 0.5, dmin = 0.25."""
+    import numpy as np
+    from oracle import dequant as dq
+    blk = np.zeros(84, np.uint8)
+    blk[0:16] = 0x21
+    blk[16:80] = 0b11100100                      # bit pairs (LSB first): 0, 1, 2, 3 for planes j = 0..3
+    blk[80:82] = np.array([0.5], "<f2").view(np.uint8)
+    blk[82:84] = np.array([0.25], "<f2").view(np.uint8)
+    out = dq.dequantize("Q2_K", blk, 256, round_f16=True).reshape(2, 4, 32)
+    for j in range(4):
+        assert np.all(out[:, j] == 0.5 * 1 * j - 0.25 * 2)
+
+
+def test_q3_k_known_answer():
+    """Hand-built Q3_K block (gguf.rs:280-366): every 6-bit scale = 33 (-> +1), d = 0.25, q2 plane j = j, high bits
+    set for the first 128 elements only (-> no -4 there, -4 in the second half)."""
+    import numpy as np
+    from oracle import dequant as dq
+    blk = np.zeros(110, np.uint8)
+    blk[0:32] = 0x0F                             # hmask bits 0..3 set: planes of n = 0
+    blk[32:96] = 0b11100100
+    # scales: low 4 bits = 1 everywhere, high 2 bits = 2 everywhere  (33 = 0b100001)
+    blk[96:104] = 0x11
+    blk[104:108] = 0b10101010
+    blk[108:110] = np.array([0.25], "<f2").view(np.uint8)
+    out = dq.dequantize("Q3_K", blk, 256, round_f16=True).reshape(2, 4, 32)
+    for j in range(4):
+        assert np.all(out[0, j] == 0.25 * 1 * j)
+        assert np.all(out[1, j] == 0.25 * 1 * (j - 4))
+
+
+def test_q2_k_q3_k_fixture_roundtrip():
+    import numpy as np
+    from oracle import dequant as dq, quantize as qz
+    w = (np.random.default_rng(5).standard_normal((4, 512)) * 0.05).astype(np.float32)
+    for kind, tol in (("Q2_K", 0.08), ("Q3_K", 0.06)):
+        raw = qz.QUANTIZE[kind](w)
+        assert raw.size == w.size // 256 * dq.BLOCK_BYTES[kind]
+        d = dq.dequantize(kind, raw, w.size, round_f16=False).reshape(w.shape)
+        assert np.abs(d - w).max() < tol, kind

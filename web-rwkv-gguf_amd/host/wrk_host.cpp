@@ -39,7 +39,7 @@ inline float bf2f(uint16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(
 inline float ld_f16(const uint8_t* p) { uint16_t b; memcpy(&b, p, 2); return h2f(b); }
 
 // ------------------------------------------------------------------ GGML types (gguf.rs:888-1075)
-enum : uint32_t { T_F32 = 0, T_F16 = 1, T_Q4_0 = 2, T_Q8_0 = 8, T_Q4K = 12, T_Q5K = 13, T_Q6K = 14, T_BF16 = 30 };
+enum : uint32_t { T_F32 = 0, T_F16 = 1, T_Q4_0 = 2, T_Q8_0 = 8, T_Q2K = 10, T_Q3K = 11, T_Q4K = 12, T_Q5K = 13, T_Q6K = 14, T_BF16 = 30 };
 size_t type_size(uint32_t t) {
     switch (t) {
         case T_F32: return 4; case T_F16: return 2; case T_BF16: return 2;
@@ -157,6 +157,67 @@ void repack_q4_0_to_nf4(const uint8_t* d, size_t n, std::vector<uint8_t>& blob) 
             return (uint8_t)best;
         };
         for (int e = 0; e < 32; ++e) packed[b * 32 + e] = nearest(val[2 * e] * inv) | (nearest(val[2 * e + 1] * inv) << 4);
+    }
+}
+
+void dequant_q2_k(const uint8_t* d, size_t n, uint16_t* out) {                  // gguf.rs:372-423
+    const long long nb = (long long)(n / 256);
+#pragma omp parallel for schedule(static)
+    for (long long b = 0; b < nb; ++b) {
+        const uint8_t* blk = d + b * 84;
+        const uint8_t* scales = blk;
+        const uint8_t* qs = blk + 16;
+        const float dd = ld_f16(blk + 80), dmin = ld_f16(blk + 82);
+        uint16_t* o = out + b * 256;
+        int is = 0;
+        for (int n128 = 0; n128 < 2; ++n128) {
+            for (int j = 0; j < 4; ++j) {
+                for (int h = 0; h < 2; ++h) {
+                    const uint8_t sc = scales[is++];
+                    const float dl = dd * (float)(sc & 0xF), ml = dmin * (float)(sc >> 4);
+                    for (int l = 0; l < 16; ++l) {
+                        const int q = (qs[n128 * 32 + h * 16 + l] >> (2 * j)) & 3;
+                        *o++ = f2h(dl * (float)q - ml);
+                    }
+                }
+            }
+        }
+    }
+}
+
+void dequant_q3_k(const uint8_t* d, size_t n, uint16_t* out) {                  // gguf.rs:280-366
+    const long long nb = (long long)(n / 256);
+#pragma omp parallel for schedule(static)
+    for (long long b = 0; b < nb; ++b) {
+        const uint8_t* blk = d + b * 110;
+        const uint8_t* hmask = blk;
+        const uint8_t* qs = blk + 32;
+        const float d_all = ld_f16(blk + 108);
+        uint32_t aux[4], tmp;
+        memcpy(&aux[0], blk + 96, 4); memcpy(&aux[1], blk + 100, 4); memcpy(&tmp, blk + 104, 4);
+        const uint32_t K1 = 0x03030303u, K2 = 0x0f0f0f0fu;
+        aux[2] = ((aux[0] >> 4) & K2) | (((tmp >> 4) & K1) << 4);
+        aux[3] = ((aux[1] >> 4) & K2) | (((tmp >> 6) & K1) << 4);
+        aux[0] = (aux[0] & K2) | (((tmp >> 0) & K1) << 4);
+        aux[1] = (aux[1] & K2) | (((tmp >> 2) & K1) << 4);
+        int8_t scales[16];
+        memcpy(scales, aux, 16);
+        uint16_t* o = out + b * 256;
+        int is = 0;
+        uint8_t m = 1;
+        for (int n128 = 0; n128 < 2; ++n128) {
+            for (int j = 0; j < 4; ++j) {
+                for (int h = 0; h < 2; ++h) {
+                    const float dl = d_all * (float)((int)scales[is++] - 32);
+                    for (int l = 0; l < 16; ++l) {
+                        const int q = (qs[n128 * 32 + h * 16 + l] >> (2 * j)) & 3;
+                        const int hv = (hmask[h * 16 + l] & m) ? 0 : -4;
+                        *o++ = f2h(dl * (float)(q + hv));
+                    }
+                }
+                m = (uint8_t)(m << 1);
+            }
+        }
     }
 }
 
@@ -473,6 +534,8 @@ struct wrk_gguf {
             case T_BF16: { const uint16_t* p = (const uint16_t*)d + skip; for (size_t i = 0; i < n; ++i) out[i] = f2h(bf2f(p[i])); break; }
             case T_Q8_0: dequant_q8_0(d, n, out.data()); break;
             case T_Q4_0: dequant_q4_0(d, n, out.data()); break;
+            case T_Q2K: dequant_q2_k(d, n, out.data()); break;
+            case T_Q3K: dequant_q3_k(d, n, out.data()); break;
             case T_Q4K: dequant_q4_k(d, n, out.data()); break;
             case T_Q5K: dequant_q5_k(d, n, out.data()); break;
             case T_Q6K: dequant_q6_k(d, n, out.data()); break;
