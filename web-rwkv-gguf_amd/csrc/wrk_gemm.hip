@@ -79,11 +79,13 @@ struct GemmBatch {
 // token index -> (t, b) of the [C, T, B] views
 __device__ __forceinline__ void tok_tb(const DTensor& d, uint32_t tok, uint32_t& t, uint32_t& b) { t = tok % d.shape[1]; b = tok / d.shape[1]; }
 
-template <int KIND, int NT>
+template <int KIND, int NT, int NW>
 __device__ __forceinline__ void gemm_body(const GemmParams& P, float (*sh_tot)[NT][4][64]) {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t r = lane & 15, g = lane >> 4;
-    // a workgroup owns 16 rows; its 4 waves split K (wave w takes every 4th block / step) and meet in LDS
+    // a workgroup owns 16 rows; its NW waves split K (wave w takes every NW-th block / step) and meet in LDS.  NW = 4, or
+    // 8 when a launch has few row tiles and long rows (ffn.value at 16 tokens: 128 workgroups x 32 blocks), so that a
+    // wave's serial chain stays ~4 blocks
     const uint32_t m0 = (blockIdx.x - P.wg_begin) * 16;
     const uint32_t row = min(m0 + r, P.m - 1);
     const uint8_t* wrow = P.w + (size_t)row * P.row_bytes;
@@ -110,7 +112,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& P, float (*sh_tot)[N
 
     if (KIND == WRK_MAT_F16) {
         const f16* wr = (const f16*)wrow;
-        for (uint32_t k0 = 32 * wave; k0 < K; k0 += 128) {
+        for (uint32_t k0 = 32 * wave; k0 < K; k0 += 32 * NW) {
             const f16x8 a = (k0 + 8 * g + 8 <= K) ? *(const f16x8*)(wr + k0 + 8 * g) : zero8;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
@@ -120,7 +122,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& P, float (*sh_tot)[N
         }
     } else if (KIND == WRK_MAT_Q8_0) {
         const uint32_t nblk = K >> 5;
-        for (uint32_t s = wave; s < nblk; s += 4) {
+        for (uint32_t s = wave; s < nblk; s += NW) {
             const u32x2 q = *(const u32x2*)(wrow + (size_t)s * 32 + 8 * g);
             // int8 -> (u - 128): subnormal u*2^-24, scaled by 2^15 to u*2^-9 (normal), minus 128*2^-9
             const f16x8 a = add8(mul8(codes8(q.x ^ 0x80808080u, q.y ^ 0x80808080u), 32768.0f), -0.25f);
@@ -139,7 +141,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& P, float (*sh_tot)[N
             }
         }
     } else if (KIND == WRK_MAT_Q6_K) {
-        for (uint32_t b = wave; b < nb; b += 4) {
+        for (uint32_t b = wave; b < nb; b += NW) {
             f32x4v acc[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
@@ -249,13 +251,13 @@ __device__ __forceinline__ void gemm_body(const GemmParams& P, float (*sh_tot)[N
                 for (int t = 0; t < NT; ++t) total[t][i] += d * acc[t][i] - dmin * amin[t][i];
             }
         };
-        const uint32_t nmine = wave < nb ? (nb - wave + 3) >> 2 : 0;      // blocks of this wave: wave, wave+4, ...
+        const uint32_t nmine = wave < nb ? (nb - wave + NW - 1) / NW : 0;      // blocks of this wave: wave, wave+NW, ...
         // prefetch depth by regime: few tokens = few waves per CU = latency-bound (deep); many tokens = register-bound
         constexpr int WD = NT == 1 ? 4 : (NT == 2 ? 2 : 1);
         WBlk W[WD];
 #pragma unroll
         for (int u = 0; u < WD; ++u)
-            if ((uint32_t)u < nmine) load_w(W[u], wave + 4 * u);
+            if ((uint32_t)u < nmine) load_w(W[u], wave + NW * u);
         if (NT <= 2) {
             constexpr int XD = NT == 1 ? 2 : 1;     // B fragments double-buffered only in the 16-token regime
             BBlk X[XD];
@@ -265,19 +267,19 @@ __device__ __forceinline__ void gemm_body(const GemmParams& P, float (*sh_tot)[N
                 for (int u = 0; u < 4; ++u) {       // unrolled by 4 so that every buffer index is a compile-time constant
                     const uint32_t i = i0 + u;
                     if (i >= nmine) break;
-                    const uint32_t b = wave + 4 * i;
-                    if (XD == 2) { if (i + 1 < nmine) load_b(X[(u + 1) % XD], b + 4); }
+                    const uint32_t b = wave + NW * i;
+                    if (XD == 2) { if (i + 1 < nmine) load_b(X[(u + 1) % XD], b + NW); }
                     else load_b(X[0], b);
                     mul_blk(W[u % WD], X[u % XD], b);
-                    if (i + WD < nmine) load_w(W[u % WD], b + 4 * WD);
+                    if (i + WD < nmine) load_w(W[u % WD], b + NW * WD);
                 }
             }
         } else {
             BBlk X;     // unused
             for (uint32_t i = 0; i < nmine; ++i) {
-                const uint32_t b = wave + 4 * i;
+                const uint32_t b = wave + NW * i;
                 mul_blk(W[0], X, b);
-                if (i + 1 < nmine) load_w(W[0], b + 4);
+                if (i + 1 < nmine) load_w(W[0], b + NW);
             }
         }
     }
@@ -294,7 +296,12 @@ __device__ __forceinline__ void gemm_body(const GemmParams& P, float (*sh_tot)[N
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) total[t][i] += (sh_tot[0][t][i][lane] + sh_tot[1][t][i][lane]) + sh_tot[2][t][i][lane];
+        for (int i = 0; i < 4; ++i) {
+            float a = 0.0f;
+#pragma unroll
+            for (int w = 0; w < NW - 1; ++w) a += sh_tot[w][t][i][lane];
+            total[t][i] += a;
+        }
 
     // store: lane owns rows m0 + 4g + (0..3) of token column r of each tile
 #pragma unroll
@@ -315,20 +322,20 @@ __device__ __forceinline__ void gemm_body(const GemmParams& P, float (*sh_tot)[N
 }
 
 // One launch, several matrices: blockIdx.x -> job (like the matvec launches), kind dispatched at run time.
-template <int NT>
-__global__ void __launch_bounds__(256) gemm_kernel(const GemmBatch B) {
-    __shared__ float sh_tot[3][NT][4][64];      // K-split partial sums of waves 1..3
+template <int NT, int NW>
+__global__ void __launch_bounds__(64 * NW) gemm_kernel(const GemmBatch B) {
+    __shared__ float sh_tot[NW - 1][NT][4][64];     // K-split partial sums of waves 1..NW-1
     int ji = 0;
 #pragma unroll
     for (int q = 1; q < GEMM_MAX_JOBS; ++q)
         if (q < B.njobs && blockIdx.x >= B.jobs[q].wg_begin) ji = q;
     const GemmParams& P = B.jobs[ji];
     switch (P.kind) {
-        case WRK_MAT_Q4_K: gemm_body<WRK_MAT_Q4_K, NT>(P, sh_tot); break;
-        case WRK_MAT_Q5_K: gemm_body<WRK_MAT_Q5_K, NT>(P, sh_tot); break;
-        case WRK_MAT_Q6_K: gemm_body<WRK_MAT_Q6_K, NT>(P, sh_tot); break;
-        case WRK_MAT_Q8_0: gemm_body<WRK_MAT_Q8_0, NT>(P, sh_tot); break;
-        default: gemm_body<WRK_MAT_F16, NT>(P, sh_tot); break;
+        case WRK_MAT_Q4_K: gemm_body<WRK_MAT_Q4_K, NT, NW>(P, sh_tot); break;
+        case WRK_MAT_Q5_K: gemm_body<WRK_MAT_Q5_K, NT, NW>(P, sh_tot); break;
+        case WRK_MAT_Q6_K: gemm_body<WRK_MAT_Q6_K, NT, NW>(P, sh_tot); break;
+        case WRK_MAT_Q8_0: gemm_body<WRK_MAT_Q8_0, NT, NW>(P, sh_tot); break;
+        default: gemm_body<WRK_MAT_F16, NT, NW>(P, sh_tot); break;
     }
 }
 
@@ -368,9 +375,13 @@ int matmul_mfma_multi(hipStream_t s, const MatJob* jobs, int njobs, int) {
         wg += (j.m + 15) / 16;
     }
     // tokens per wave: enough tiles to amortise the decode, few enough to keep >= ~2 waves per SIMD
-    if (n > 64) gemm_kernel<4><<<dim3(wg, (n + 63) / 64), 256, 0, s>>>(B);
-    else if (n > 16) gemm_kernel<2><<<dim3(wg, (n + 31) / 32), 256, 0, s>>>(B);
-    else gemm_kernel<1><<<dim3(wg, (n + 15) / 16), 256, 0, s>>>(B);
+    // few row tiles x long rows (decode batches through ffn.value): 8 waves split K so a wave's serial chain is short
+    uint32_t kmax = 0;
+    for (int q = 0; q < njobs; ++q) kmax = jobs[q].k > kmax ? jobs[q].k : kmax;
+    const bool deep = wg < 256 && kmax >= 4096;
+    if (n > 64) gemm_kernel<4, 4><<<dim3(wg, (n + 63) / 64), 256, 0, s>>>(B);
+    else if (n > 16) { if (deep) gemm_kernel<2, 8><<<dim3(wg, (n + 31) / 32), 512, 0, s>>>(B); else gemm_kernel<2, 4><<<dim3(wg, (n + 31) / 32), 256, 0, s>>>(B); }
+    else { if (deep) gemm_kernel<1, 8><<<dim3(wg, (n + 15) / 16), 512, 0, s>>>(B); else gemm_kernel<1, 4><<<dim3(wg, (n + 15) / 16), 256, 0, s>>>(B); }
     return 0;
 }
 
