@@ -125,3 +125,45 @@ def test_gemm_activation_residual_f16_out_and_vec_agreement(ctx):
     mat.matmul_op(ctx.tensor(x, [k, T, 1]), b, "squared_relu", turbo=False)
     ga, gb = a.back().astype(np.float32), b.back().astype(np.float32)
     assert np.all(np.abs(ga - gb) <= np.maximum(np.abs(gb), 2.0 ** -14) * 2.0 ** -10 + 1e-6)     # <= 1 f16 ulp apart
+
+
+@pytest.mark.parametrize("kind,k,m", [("Q4_K", 2048, 130), ("Q5_K", 1024, 200), ("Q4_K", 256, 64), ("Q5_K", 2560, 72)])
+@pytest.mark.parametrize("T", [48, 64, 100, 200])
+def test_gemm_prefill_tile_kernel(ctx, kind, k, m, T):
+    """The LDS-tiled prefill kernel (>= 48 stacked tokens of one dense [K, T, 1] stack, >= 64 rows, Q4_K / Q5_K):
+    ragged row and token tails, fused activation + residual with f16 output."""
+    raw = make(kind, k, m, k + m + T)
+    mat = wrk.Matrix(ctx, kind, k, m, raw)
+    w = dq.dequantize(kind, raw, k * m, round_f16=False).reshape(m, k)
+    x = np.random.default_rng(T).standard_normal((T, k)).astype(np.float16)
+    out = ctx.zeros([m, T, 1], np.float32)
+    mat.matmul_op(ctx.tensor(x, [k, T, 1]), out, turbo=True)
+    got = out.back().reshape(T, m)
+    want = x.astype(np.float64) @ w.astype(np.float64).T
+    bound = 4e-6 * (np.abs(x).astype(np.float64) @ np.abs(w).astype(np.float64).T) + 1e-6
+    assert np.all(np.abs(got - want) <= bound), np.abs(got - want).max()
+    # x += W . relu(x)^2-style epilogue through the op-level residual of the model path is covered by the model tests;
+    # here: activation + f16 store agree with the K-split kernel to one f16 ulp
+    a, b = ctx.zeros([m, T, 1]), ctx.zeros([m, T, 1])
+    mat.matmul_op(ctx.tensor(x, [k, T, 1]), a, "tanh", turbo=True)
+    mat.matmul_op(ctx.tensor(x, [k, T, 1]), b, "tanh", turbo=False)
+    ga, gb = a.back().astype(np.float32), b.back().astype(np.float32)
+    # both f32 pre-activations are within `bound` of the exact value (tanh' <= 1), then each is rounded to f16
+    d = np.abs(ga.reshape(T, m) - gb.reshape(T, m))
+    ok = d <= np.maximum(np.abs(gb.reshape(T, m)), 2.0 ** -14) * 2.0 ** -10 + 2.0 * bound + 1e-6
+    assert np.all(ok), (int((~ok).sum()), float(d.max()))
+
+
+def test_gemm_prefill_tile_kernel_model_shape(ctx):
+    """A shape the dispatcher really sends to the tile kernel at K = 2048 (>= 128 tiles): 2048 x 2048 x 256 tokens."""
+    kind, k, m, T = "Q4_K", 2048, 2048, 256
+    raw = make(kind, k, m, 77)
+    mat = wrk.Matrix(ctx, kind, k, m, raw)
+    w = dq.dequantize(kind, raw, k * m, round_f16=False).reshape(m, k)
+    x = np.random.default_rng(9).standard_normal((T, k)).astype(np.float16)
+    out = ctx.zeros([m, T, 1], np.float32)
+    mat.matmul_op(ctx.tensor(x, [k, T, 1]), out, turbo=True)
+    got = out.back().reshape(T, m)
+    want = x.astype(np.float64) @ w.astype(np.float64).T
+    bound = 4e-6 * (np.abs(x).astype(np.float64) @ np.abs(w).astype(np.float64).T) + 1e-6
+    assert np.all(np.abs(got - want) <= bound), np.abs(got - want).max()

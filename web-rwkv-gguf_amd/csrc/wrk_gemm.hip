@@ -339,6 +339,146 @@ __global__ void __launch_bounds__(64 * NW) gemm_kernel(const GemmBatch B) {
     }
 }
 
+// ------------------------------------------------------------------ prefill tile kernel (Q4_K / Q5_K, >= 96 tokens)
+// The K-split kernel above re-reads the whole activation tile from L2 for every 16 rows (rocprof: 1 GB of L2->L1
+// traffic for an 8192x2048 matrix x 512 tokens -- the limiter, not the matrix core).  Here a workgroup owns
+// 64 rows x 64 tokens: its 4 waves take 16 rows each over the WHOLE K and share the activation tile through LDS
+// ([64 tokens][256 k] f16 per 256-block, double buffered: 2 x 33 KB, two workgroups per CU; rows padded by 16 B so the B-fragment reads of a
+// 16-lane phase hit 16 distinct bank groups).  Per block and wave: 64 MFMAs (4 steps x 4 token tiles x {lo, hi,
+// min-lo, min-hi}) against 32 ds_read_b128 -- MFMA and LDS time are balanced.  The next block's activations are
+// fetched into registers (and its weights requested) while the current one is multiplied.
+constexpr int TILE_TOK = 64, TILE_TT = TILE_TOK / 16, TILE_ROWS = 64, TILE_LDS_ROW = 256 + 8;     // f16 elements per staged token row
+constexpr int TILE_STAGE = TILE_TOK * 32 / 256;      // 16-byte chunks each thread stages per block
+
+template <int KIND>
+__device__ __forceinline__ void gemm_tile_body(const GemmParams& P, f16* __restrict__ lds) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t r = lane & 15, g = lane >> 4;
+    const uint32_t m0 = (blockIdx.x - P.wg_begin) * TILE_ROWS + wave * 16;     // this wave's 16 rows
+    const uint32_t n0 = blockIdx.y * TILE_TOK;
+    const uint32_t K = P.k, nb = K >> 8;
+    const uint32_t row = min(m0 + r, P.m - 1);
+    const uint8_t* wrow = P.w + (size_t)row * P.row_bytes;
+    const uint32_t hoff = KIND == WRK_MAT_Q4_K ? nb * 128 : nb * 160, soff = hoff + nb * 4;
+    const uint8_t* crow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) crow[i] = P.w + (size_t)min(m0 + 4 * g + i, P.m - 1) * P.row_bytes + hoff;
+
+    // activation staging: 64 tokens x 32 chunks of 8 f16 per block, 8 per thread: chunk q -> token (tid >> 5) + 8 q,
+    // columns 8 (tid & 31).  The input is a dense [K, T, 1] stack (checked on the host): token rows are xs0 apart.
+    const size_t xs0 = P.in.stride[0];
+    const f16* xbase = (const f16*)P.in.p + dt_index(P.in, 0, 0, 0) + (size_t)(n0 + (tid >> 5)) * xs0 + (tid & 31u) * 8;
+    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    f16x8 stage[TILE_STAGE];
+    auto fetch_x = [&](uint32_t b) {
+#pragma unroll
+        for (int q = 0; q < TILE_STAGE; ++q)
+            stage[q] = (n0 + (tid >> 5) + 8 * q < P.n) ? *(const f16x8*)(xbase + (size_t)8 * q * xs0 + (size_t)b * 256) : zero8;
+    };
+    auto store_x = [&](uint32_t buf) {
+        f16* base = lds + (size_t)buf * TILE_TOK * TILE_LDS_ROW;
+#pragma unroll
+        for (int q = 0; q < TILE_STAGE; ++q) *(f16x8*)(base + ((tid >> 5) + 8 * q) * TILE_LDS_ROW + (tid & 31u) * 8) = stage[q];
+    };
+
+    struct WBlk { u32x2 q[4]; u32x2 qh; u32x4 sm; uint32_t dd[4]; };
+    auto load_w = [&](WBlk& R, uint32_t b) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) R.q[j] = *(const u32x2*)(wrow + (size_t)b * 128 + j * 32 + 8 * g);
+        if (KIND == WRK_MAT_Q5_K) R.qh = *(const u32x2*)(wrow + (size_t)nb * 128 + (size_t)b * 32 + 8 * g);
+        R.sm = *(const u32x4*)(wrow + soff + (size_t)b * 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) R.dd[i] = *(const uint32_t*)(crow[i] + (size_t)b * 4);
+    };
+
+    f32x4v total[TILE_TT];
+#pragma unroll
+    for (int t = 0; t < TILE_TT; ++t) total[t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+
+    WBlk W0, W1;
+    load_w(W0, 0);
+    fetch_x(0);
+    store_x(0);
+    __syncthreads();
+    // one 256-block: multiply block b out of LDS buffer `buf` with weights R while the next block's weights (into Rn)
+    // and activations (into `stage`) are in flight; buffers alternate by unrolling, so no register array is indexed
+    auto step = [&](uint32_t b, uint32_t buf, const WBlk& R, WBlk& Rn) {
+        const bool more = b + 1 < nb;
+        if (more) { load_w(Rn, b + 1); fetch_x(b + 1); }
+        const f16* xt = lds + (size_t)buf * TILE_TOK * TILE_LDS_ROW + r * TILE_LDS_ROW + 8 * g;
+        f32x4v acc[TILE_TT], amin[TILE_TT];
+#pragma unroll
+        for (int t = 0; t < TILE_TT; ++t) { acc[t] = (f32x4v){0.f, 0.f, 0.f, 0.f}; amin[t] = (f32x4v){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const u32x2 q = R.q[j];
+            const uint32_t v = R.sm[j];
+            const float sc0 = (float)(v & 0xffu), sc1 = (float)((v >> 8) & 0xffu);
+            f16x8 alo, ahi;
+            if (KIND == WRK_MAT_Q4_K) {
+                alo = mul8(codes8(q.x & 0x0f0f0f0fu, q.y & 0x0f0f0f0fu), sc0 * 1024.0f);
+                ahi = mul8(codes8(q.x & 0xf0f0f0f0u, q.y & 0xf0f0f0f0u), sc1 * 64.0f);
+            } else {
+                const uint32_t s0 = 2 * j, s1 = 2 * j + 1;
+                alo = mul8(codes8((q.x & 0x0f0f0f0fu) | (((R.qh.x >> s0) & 0x01010101u) << 4), (q.y & 0x0f0f0f0fu) | (((R.qh.y >> s0) & 0x01010101u) << 4)), sc0 * 1024.0f);
+                ahi = mul8(codes8(((q.x >> 4) & 0x0f0f0f0fu) | (((R.qh.x >> s1) & 0x01010101u) << 4), ((q.y >> 4) & 0x0f0f0f0fu) | (((R.qh.y >> s1) & 0x01010101u) << 4)), sc1 * 1024.0f);
+            }
+            const f16 m0h = (f16)(float)((v >> 16) & 0xffu), m1h = (f16)(float)(v >> 24);
+            const f16x8 mlo = {m0h, m0h, m0h, m0h, m0h, m0h, m0h, m0h}, mhi = {m1h, m1h, m1h, m1h, m1h, m1h, m1h, m1h};
+#pragma unroll
+            for (int t = 0; t < TILE_TT; ++t) {
+                const f16x8 b0 = *(const f16x8*)(xt + (size_t)t * 16 * TILE_LDS_ROW + j * 64);
+                const f16x8 b1 = *(const f16x8*)(xt + (size_t)t * 16 * TILE_LDS_ROW + j * 64 + 32);
+                acc[t] = mfma16(alo, b0, acc[t]);
+                acc[t] = mfma16(ahi, b1, acc[t]);
+                amin[t] = mfma16(mlo, b0, amin[t]);
+                amin[t] = mfma16(mhi, b1, amin[t]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float d = (float)__builtin_bit_cast(f16, (uint16_t)(R.dd[i] & 0xffffu)) * 16384.0f;
+            const float dmin = (float)__builtin_bit_cast(f16, (uint16_t)(R.dd[i] >> 16));
+#pragma unroll
+            for (int t = 0; t < TILE_TT; ++t) total[t][i] += d * acc[t][i] - dmin * amin[t][i];
+        }
+        if (more) store_x(buf ^ 1u);        // the other buffer was last read in iteration b - 1 (the barrier orders it)
+        __syncthreads();
+    };
+    for (uint32_t b = 0; b < nb; b += 2) {
+        step(b, 0u, W0, W1);
+        if (b + 1 < nb) step(b + 1, 1u, W1, W0);
+    }
+
+    // store: lane owns rows m0 + 4g + (0..3) of token column r of each 16-token tile
+#pragma unroll
+    for (int t = 0; t < TILE_TT; ++t) {
+        const uint32_t tok = n0 + 16 * t + r;
+        if (tok >= P.n) continue;
+        uint32_t tt, bb;
+        tok_tb(P.out, tok, tt, bb);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t mr = m0 + 4 * g + i;
+            if (mr >= P.m) continue;
+            float o = act_apply(P.act, total[t][i]);
+            if (P.has_res) { uint32_t rt, rb; tok_tb(P.res, tok, rt, rb); o = dt_round(P.out, o) + dt_load(P.res, dt_index(P.res, mr, rt, rb)); }
+            dt_store(P.out, dt_index(P.out, mr, tt, bb), o);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) gemm_tile_kernel(const GemmBatch B) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char tile_smem[];
+    int ji = 0;
+#pragma unroll
+    for (int q = 1; q < GEMM_MAX_JOBS; ++q)
+        if (q < B.njobs && blockIdx.x >= B.jobs[q].wg_begin) ji = q;
+    const GemmParams& P = B.jobs[ji];
+    if (P.kind == WRK_MAT_Q4_K) gemm_tile_body<WRK_MAT_Q4_K>(P, (f16*)tile_smem);
+    else gemm_tile_body<WRK_MAT_Q5_K>(P, (f16*)tile_smem);
+}
+
 // fewest stacked tokens sent to the matrix cores (tiles are padded to 16 tokens; below this the matvec kernels run)
 uint32_t gemm_min_tokens() {
     static const uint32_t v = [] { const char* e = getenv("WRK_GEMM_MIN"); const int x = e ? atoi(e) : 4; return (uint32_t)(x < 2 ? 2 : x); }();     // measured: B=4 break-even, B=8 2x in favour of MFMA
@@ -359,29 +499,49 @@ static bool gemm_ok(const MatJob& j, uint32_t n) {
 
 // All jobs multiply the same number of tokens; they run in ONE launch.  Returns -2 when any job is not for the MFMA
 // path (n < 16, ROUND_F16, non-f16 / unaligned input, K % 32, Int8 / NF4): the caller falls back to the matvec kernels.
+static void fill_job(GemmParams& P, const MatJob& j, uint32_t n, uint32_t wg_begin) {
+    P.w = j.w; P.kind = j.kind; P.k = j.k; P.m = j.m; P.row_bytes = j.row_bytes; P.act = j.act; P.n = n;
+    P.has_res = j.has_res; P.in = j.in; P.out = j.out; P.res = j.res; P.wg_begin = wg_begin;
+}
+
 int matmul_mfma_multi(hipStream_t s, const MatJob* jobs, int njobs, int) {
     if (njobs <= 0 || njobs > GEMM_MAX_JOBS) return -2;
     const uint32_t n = jobs[0].in.shape[1] * jobs[0].in.shape[2];
     for (int j = 0; j < njobs; ++j)
         if (!gemm_ok(jobs[j], n)) return -2;
-    GemmBatch B;
-    B.njobs = njobs;
-    uint32_t wg = 0;
+    // prefill regime: Q4_K / Q5_K matrices with >= 64 rows go to the LDS-tiled kernel, the rest (LoRA, Q6_K, Q8_0, F16)
+    // to the K-split kernel, each group in one launch
+    static const bool use_tile = [] { const char* e = getenv("WRK_GEMM_TILE"); return !(e && e[0] == '0'); }();
+    GemmBatch T, B;
+    T.njobs = B.njobs = 0;
+    uint32_t twg = 0, wg = 0, kmax = 0;
     for (int q = 0; q < njobs; ++q) {
         const MatJob& j = jobs[q];
-        GemmParams& P = B.jobs[q];
-        P.w = j.w; P.kind = j.kind; P.k = j.k; P.m = j.m; P.row_bytes = j.row_bytes; P.act = j.act; P.n = n;
-        P.has_res = j.has_res; P.in = j.in; P.out = j.out; P.res = j.res; P.wg_begin = wg;
-        wg += (j.m + 15) / 16;
+        // the tile kernel walks the whole K in every wave: it needs enough workgroups to fill the chip (a 2048 x 8192
+        // matrix x 128 tokens has only 64 tiles and is faster on the K-split kernel: 44 vs 74 us)
+        const uint32_t tiles = ((j.m + TILE_ROWS - 1) / TILE_ROWS) * ((n + TILE_TOK - 1) / TILE_TOK);
+        const bool tile = use_tile && n >= 48 && (j.kind == WRK_MAT_Q4_K || j.kind == WRK_MAT_Q5_K) && j.m >= 64 && j.in.shape[2] == 1 &&
+                          (tiles >= 128 || j.k <= 2560);      // <= 10 blocks per wave: the serial walk is short anyway
+        if (tile) { fill_job(T.jobs[T.njobs++], j, n, twg); twg += (j.m + TILE_ROWS - 1) / TILE_ROWS; }
+        else { fill_job(B.jobs[B.njobs++], j, n, wg); wg += (j.m + 15) / 16; kmax = j.k > kmax ? j.k : kmax; }
     }
-    // tokens per wave: enough tiles to amortise the decode, few enough to keep >= ~2 waves per SIMD
-    // few row tiles x long rows (decode batches through ffn.value): 8 waves split K so a wave's serial chain is short
-    uint32_t kmax = 0;
-    for (int q = 0; q < njobs; ++q) kmax = jobs[q].k > kmax ? jobs[q].k : kmax;
-    const bool deep = wg < 256 && kmax >= 4096;
-    if (n > 64) gemm_kernel<4, 4><<<dim3(wg, (n + 63) / 64), 256, 0, s>>>(B);
-    else if (n > 16) { if (deep) gemm_kernel<2, 8><<<dim3(wg, (n + 31) / 32), 512, 0, s>>>(B); else gemm_kernel<2, 4><<<dim3(wg, (n + 31) / 32), 256, 0, s>>>(B); }
-    else { if (deep) gemm_kernel<1, 8><<<dim3(wg, (n + 15) / 16), 512, 0, s>>>(B); else gemm_kernel<1, 4><<<dim3(wg, (n + 15) / 16), 256, 0, s>>>(B); }
+    if (T.njobs) {
+        const size_t smem = (size_t)2 * TILE_TOK * TILE_LDS_ROW * sizeof(f16);       // 67 584 B
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void*)gemm_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -1;
+            attr_set = true;
+        }
+        gemm_tile_kernel<<<dim3(twg, (n + TILE_TOK - 1) / TILE_TOK), 256, smem, s>>>(T);
+    }
+    if (B.njobs) {
+        // tokens per wave: enough tiles to amortise the decode, few enough to keep >= ~2 waves per SIMD;
+        // few row tiles x long rows (decode batches through ffn.value): 8 waves split K so a wave's serial chain is short
+        const bool deep = wg < 256 && kmax >= 4096;
+        if (n > 64) gemm_kernel<4, 4><<<dim3(wg, (n + 63) / 64), 256, 0, s>>>(B);
+        else if (n > 16) { if (deep) gemm_kernel<2, 8><<<dim3(wg, (n + 31) / 32), 512, 0, s>>>(B); else gemm_kernel<2, 4><<<dim3(wg, (n + 31) / 32), 256, 0, s>>>(B); }
+        else { if (deep) gemm_kernel<1, 8><<<dim3(wg, (n + 15) / 16), 512, 0, s>>>(B); else gemm_kernel<1, 4><<<dim3(wg, (n + 15) / 16), 256, 0, s>>>(B); }
+    }
     return 0;
 }
 

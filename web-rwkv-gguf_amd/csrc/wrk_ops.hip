@@ -243,10 +243,102 @@ __global__ void __launch_bounds__(256) time_mix_v7_kernel(const uint32_t* __rest
     for (int jj = 0; jj < 16; ++jj) dt_store(st, dt_index(st, ch, 1 + g * 16 + jj, cur.batch), Sreg[jj]);
 }
 
+
+// Fast path for the layout the runtime uses (dense f16 r, w, n, x; f32 state): same arithmetic, different mapping.
+// Thread (i = tid >> 2, part = tid & 3) owns S[16 part .. 16 part + 15][i], so the two reductions over j are 16
+// in-register FMAs plus two quad shuffles -- no LDS traffic and no workgroup barrier for them.  Only w~ (two
+// transcendentals per key channel) is prepared cooperatively: thread j < 64 computes w~[j] of the NEXT token into a
+// double-buffered LDS row, one barrier per token.  The f16 inputs of the next token are prefetched while the current
+// one is multiplied.  Measured (1.5B, 128-token chunk): 292 us -> see DESIGN.md.
+__global__ void __launch_bounds__(256) time_mix_v7_fast_kernel(const uint32_t* __restrict__ cursors, DTensor st, DTensor r, DTensor w,
+                                                                DTensor n, DTensor x) {
+    constexpr int S = 64;
+    __shared__ __attribute__((aligned(16))) float sh_w[2][S];
+    const uint32_t head = blockIdx.x, t0 = blockIdx.y;
+    const Cursor cur = unpack_cursor(cursors[t0]);
+    if (cur.token != t0) return;                     // not the first token of a sequence chunk
+    const uint32_t tid = threadIdx.x, i = tid >> 2, part = tid & 3u;
+    const uint32_t ch = head * S + i;
+    const uint32_t tend = cur.token + cur.len;
+
+    // token-shift carry: state row 0 <- att_x of the sequence's last token (read before it is overwritten)
+    if (part == 0) dt_store(st, dt_index(st, ch, 0, cur.batch), dt_load(x, dt_index(x, i, head, tend - 1)));
+    float Sreg[16];
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) Sreg[jj] = dt_load(st, dt_index(st, ch, 1 + part * 16 + jj, cur.batch));
+
+    struct Tok { f16x8 r[2], k[2], a[2], kk[2]; f16 v; f16 wraw; };
+    // per-token pointers advance by constant strides (dense f16 views): no index arithmetic inside the loop
+    const size_t rstep = (size_t)r.stride[1] * r.stride[0], nstep = (size_t)n.stride[1] * n.stride[0];
+    const size_t wstep = (size_t)w.stride[1] * w.stride[0], xstep = (size_t)x.stride[1] * x.stride[0];
+    const f16* rp = (const f16*)r.p + dt_index(r, part * 16, head, cur.token);
+    const f16* kp = (const f16*)n.p + dt_index4(n, part * 16, head, cur.token, 0);
+    const f16* ap = (const f16*)n.p + dt_index4(n, part * 16, head, cur.token, 2);
+    const f16* qp = (const f16*)n.p + dt_index4(n, part * 16, head, cur.token, 3);
+    const f16* vp = (const f16*)n.p + dt_index4(n, i, head, cur.token, 1);
+    const f16* wp = (const f16*)w.p + dt_index(w, tid & 63u, head, cur.token);
+    f16* xp = (f16*)x.p + dt_index(x, i, head, cur.token);
+    auto load_tok = [&](Tok& T) {       // loads the token the pointers stand on, then advances them
+        T.r[0] = *(const f16x8*)rp; T.r[1] = *(const f16x8*)(rp + 8);
+        T.k[0] = *(const f16x8*)kp; T.k[1] = *(const f16x8*)(kp + 8);
+        T.a[0] = *(const f16x8*)ap; T.a[1] = *(const f16x8*)(ap + 8);
+        T.kk[0] = *(const f16x8*)qp; T.kk[1] = *(const f16x8*)(qp + 8);
+        T.v = *vp;
+        if (tid < S) T.wraw = *wp;
+        rp += rstep; kp += nstep; ap += nstep; qp += nstep; vp += nstep; wp += wstep;
+    };
+    Tok curT, nxtT;
+    load_tok(curT);
+    if (tid < S) sh_w[cur.token & 1u][tid] = __expf(-0.606531f * act_sigmoid((float)curT.wraw));
+    for (uint32_t t = cur.token; t < tend; ++t) {
+        const bool more = t + 1 < tend;
+        if (more) load_tok(nxtT);
+        __syncthreads();                                        // w~ of token t is in sh_w[t & 1]
+        const float* wt = sh_w[t & 1u] + part * 16;
+        float wv[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const f32x4 v4 = *(const f32x4*)(wt + 4 * q); wv[4 * q] = v4[0]; wv[4 * q + 1] = v4[1]; wv[4 * q + 2] = v4[2]; wv[4 * q + 3] = v4[3]; }
+        // four independent FMA chains per reduction (a wave runs alone on its SIMD: latency, not issue, is the cost)
+        float kkf[16], s4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) { kkf[jj] = (float)curT.kk[jj >> 3][jj & 7]; s4[jj & 3] = __builtin_fmaf(Sreg[jj], -kkf[jj], s4[jj & 3]); }   // a~ = -kk
+        float sa = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+        sa = (sa + __shfl_xor(sa, 1, WAVE));
+        sa = (sa + __shfl_xor(sa, 2, WAVE));
+        const float vv = (float)curT.v;
+        float y4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) {
+            const float kj = (float)curT.k[jj >> 3][jj & 7], aj = (float)curT.a[jj >> 3][jj & 7];
+            const float sn = Sreg[jj] * wv[jj] + kj * vv + sa * (kkf[jj] * aj);                                  // b~ = kk * a
+            Sreg[jj] = sn;
+            y4[jj & 3] = __builtin_fmaf((float)curT.r[jj >> 3][jj & 7], sn, y4[jj & 3]);
+        }
+        float y = (y4[0] + y4[1]) + (y4[2] + y4[3]);
+        y = (y + __shfl_xor(y, 1, WAVE));
+        y = (y + __shfl_xor(y, 2, WAVE));
+        if (part == 0) *xp = (f16)y;
+        xp += xstep;
+        if (more) {
+            if (tid < S) sh_w[(t + 1) & 1u][tid] = __expf(-0.606531f * act_sigmoid((float)nxtT.wraw));
+            curT = nxtT;
+        }
+    }
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) dt_store(st, dt_index(st, ch, 1 + part * 16 + jj, cur.batch), Sreg[jj]);
+}
+
+static bool dense_f16_heads(const DTensor& d) {
+    return d.dtype == WRK_F16 && d.shape[0] == 64 && d.stride[0] == 64 && d.offset[0] == 0 && (((uintptr_t)d.p) & 15u) == 0;
+}
+
 void time_mix_v7(hipStream_t s, const uint32_t* cursors, DTensor st, DTensor r, DTensor w, DTensor n, DTensor x) {
     if (r.shape[2] == 0) return;
     dim3 grid(r.shape[1], r.shape[2]);
-    time_mix_v7_kernel<<<grid, 256, 0, s>>>(cursors, st, r, w, n, x);
+    if (dense_f16_heads(r) && dense_f16_heads(w) && dense_f16_heads(n) && dense_f16_heads(x) && st.dtype == WRK_F32)
+        time_mix_v7_fast_kernel<<<grid, 256, 0, s>>>(cursors, st, r, w, n, x);
+    else
+        time_mix_v7_kernel<<<grid, 256, 0, s>>>(cursors, st, r, w, n, x);
 }
 
 // ------------------------------------------------------------------ time_first_v7 (time_mix_v7.wgsl:223-262)
