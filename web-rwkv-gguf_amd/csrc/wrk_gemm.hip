@@ -373,7 +373,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmParams& P, f16* __restr
     auto fetch_x = [&](uint32_t b) {
 #pragma unroll
         for (int q = 0; q < TILE_STAGE; ++q)
-            stage[q] = (n0 + (tid >> 5) + 8 * q < P.n) ? *(const f16x8*)(xbase + (size_t)8 * q * xs0 + (size_t)b * 256) : zero8;
+            stage[q] = (n0 + (tid >> 5) + 8 * q < P.n && b * 256 + (tid & 31u) * 8 < K) ? *(const f16x8*)(xbase + (size_t)8 * q * xs0 + (size_t)b * 256) : zero8;
     };
     auto store_x = [&](uint32_t buf) {
         f16* base = lds + (size_t)buf * TILE_TOK * TILE_LDS_ROW;
@@ -468,6 +468,74 @@ __device__ __forceinline__ void gemm_tile_body(const GemmParams& P, f16* __restr
     }
 }
 
+// F16 matrices (the LoRA projections: 2048 -> 96..256 and back) on the same tiling: A fragments are plain loads, K need
+// not be a multiple of 256 (fragments and staged activations beyond K are zero).
+__device__ __forceinline__ void gemm_tile_body_f16(const GemmParams& P, f16* __restrict__ lds) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t r = lane & 15, g = lane >> 4;
+    const uint32_t m0 = (blockIdx.x - P.wg_begin) * TILE_ROWS + wave * 16;
+    const uint32_t n0 = blockIdx.y * TILE_TOK;
+    const uint32_t K = P.k, nb = (K + 255) >> 8;
+    const f16* wr = (const f16*)(P.w + (size_t)min(m0 + r, P.m - 1) * P.row_bytes);
+    const size_t xs0 = P.in.stride[0];
+    const f16* xbase = (const f16*)P.in.p + dt_index(P.in, 0, 0, 0) + (size_t)(n0 + (tid >> 5)) * xs0 + (tid & 31u) * 8;
+    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    f16x8 stage[TILE_STAGE];
+    auto fetch_x = [&](uint32_t b) {
+#pragma unroll
+        for (int q = 0; q < TILE_STAGE; ++q)
+            stage[q] = (n0 + (tid >> 5) + 8 * q < P.n && b * 256 + (tid & 31u) * 8 < K) ? *(const f16x8*)(xbase + (size_t)8 * q * xs0 + (size_t)b * 256) : zero8;
+    };
+    auto store_x = [&](uint32_t buf) {
+        f16* base = lds + (size_t)buf * TILE_TOK * TILE_LDS_ROW;
+#pragma unroll
+        for (int q = 0; q < TILE_STAGE; ++q) *(f16x8*)(base + ((tid >> 5) + 8 * q) * TILE_LDS_ROW + (tid & 31u) * 8) = stage[q];
+    };
+    struct FBlk { f16x8 a[8]; };
+    auto load_w = [&](FBlk& R, uint32_t b) {
+#pragma unroll
+        for (int sb = 0; sb < 8; ++sb) { const uint32_t k = b * 256 + sb * 32 + 8 * g; R.a[sb] = (k + 8 <= K) ? *(const f16x8*)(wr + k) : zero8; }
+    };
+    f32x4v total[TILE_TT];
+#pragma unroll
+    for (int t = 0; t < TILE_TT; ++t) total[t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+    FBlk W0, W1;
+    load_w(W0, 0);
+    fetch_x(0);
+    store_x(0);
+    __syncthreads();
+    auto step = [&](uint32_t b, uint32_t buf, const FBlk& R, FBlk& Rn) {
+        const bool more = b + 1 < nb;
+        if (more) { load_w(Rn, b + 1); fetch_x(b + 1); }
+        const f16* xt = lds + (size_t)buf * TILE_TOK * TILE_LDS_ROW + r * TILE_LDS_ROW + 8 * g;
+#pragma unroll
+        for (int sb = 0; sb < 8; ++sb)
+#pragma unroll
+            for (int t = 0; t < TILE_TT; ++t) total[t] = mfma16(R.a[sb], *(const f16x8*)(xt + (size_t)t * 16 * TILE_LDS_ROW + sb * 32), total[t]);
+        if (more) store_x(buf ^ 1u);
+        __syncthreads();
+    };
+    for (uint32_t b = 0; b < nb; b += 2) {
+        step(b, 0u, W0, W1);
+        if (b + 1 < nb) step(b + 1, 1u, W1, W0);
+    }
+#pragma unroll
+    for (int t = 0; t < TILE_TT; ++t) {
+        const uint32_t tok = n0 + 16 * t + r;
+        if (tok >= P.n) continue;
+        uint32_t tt, bb;
+        tok_tb(P.out, tok, tt, bb);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t mr = m0 + 4 * g + i;
+            if (mr >= P.m) continue;
+            float o = act_apply(P.act, total[t][i]);
+            if (P.has_res) { uint32_t rt, rb; tok_tb(P.res, tok, rt, rb); o = dt_round(P.out, o) + dt_load(P.res, dt_index(P.res, mr, rt, rb)); }
+            dt_store(P.out, dt_index(P.out, mr, tt, bb), o);
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) gemm_tile_kernel(const GemmBatch B) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tile_smem[];
     int ji = 0;
@@ -476,7 +544,8 @@ __global__ void __launch_bounds__(256) gemm_tile_kernel(const GemmBatch B) {
         if (q < B.njobs && blockIdx.x >= B.jobs[q].wg_begin) ji = q;
     const GemmParams& P = B.jobs[ji];
     if (P.kind == WRK_MAT_Q4_K) gemm_tile_body<WRK_MAT_Q4_K>(P, (f16*)tile_smem);
-    else gemm_tile_body<WRK_MAT_Q5_K>(P, (f16*)tile_smem);
+    else if (P.kind == WRK_MAT_Q5_K) gemm_tile_body<WRK_MAT_Q5_K>(P, (f16*)tile_smem);
+    else gemm_tile_body_f16(P, (f16*)tile_smem);
 }
 
 // fewest stacked tokens sent to the matrix cores (tiles are padded to 16 tokens; below this the matvec kernels run)
@@ -520,8 +589,8 @@ int matmul_mfma_multi(hipStream_t s, const MatJob* jobs, int njobs, int) {
         // the tile kernel walks the whole K in every wave: it needs enough workgroups to fill the chip (a 2048 x 8192
         // matrix x 128 tokens has only 64 tiles and is faster on the K-split kernel: 44 vs 74 us)
         const uint32_t tiles = ((j.m + TILE_ROWS - 1) / TILE_ROWS) * ((n + TILE_TOK - 1) / TILE_TOK);
-        const bool tile = use_tile && n >= 48 && (j.kind == WRK_MAT_Q4_K || j.kind == WRK_MAT_Q5_K) && j.m >= 64 && j.in.shape[2] == 1 &&
-                          (tiles >= 128 || j.k <= 2560);      // <= 10 blocks per wave: the serial walk is short anyway
+        const bool tile = use_tile && n >= 48 && (j.kind == WRK_MAT_Q4_K || j.kind == WRK_MAT_Q5_K || j.kind == WRK_MAT_F16) && j.m >= 64 &&
+                          j.in.shape[2] == 1 && (tiles >= 128 || j.k <= 2560);      // <= 10 blocks per wave: the serial walk is short anyway
         if (tile) { fill_job(T.jobs[T.njobs++], j, n, twg); twg += (j.m + TILE_ROWS - 1) / TILE_ROWS; }
         else { fill_job(B.jobs[B.njobs++], j, n, wg); wg += (j.m + 15) / 16; kmax = j.k > kmax ? j.k : kmax; }
     }
