@@ -681,14 +681,14 @@ __device__ __forceinline__ void matvec_body_reg(const JobDev& J, unsigned char* 
     // and the first row's dot product can start as soon as that row is in (WRK_TIMING: weights-first cost ~1 us).
     const f16* xin = (const f16*)J.in.p + dt_index(J.in, 0, 0, 0);
     XRegs x[XI];
-    float res_pre[RB], carry_pre[RB];
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb) {
-        res_pre[rb] = carry_pre[rb] = 0.0f;
-        const uint32_t r = KS == 1 ? row_of(rb) : r0 + tid;
-        const bool mine = KS == 1 ? (uint32_t)rb < nrows : (rb == 0 && tid < nrows);
-        if (mine && J.has_res) res_pre[rb] = dt_load(J.res, dt_index(J.res, r, 0, 0));
-        if (mine && J.carry_dst) carry_pre[rb] = (float)J.carry_src[r];
+    // epilogue operands: the thread that will finish a row fetches that row's residual / carry value now.
+    // KS == 1: lane rb (< RB) of a wave finishes the wave's rb-th row; KS == 4: thread tid finishes row r0 + tid.
+    float res_pre = 0.0f, carry_pre = 0.0f;
+    {
+        const uint32_t r = KS == 1 ? row_of(lane) : r0 + tid;
+        const bool mine = KS == 1 ? (lane < (uint32_t)RB && lane < nrows) : tid < nrows;
+        if (mine && J.has_res) res_pre = dt_load(J.res, dt_index(J.res, r, 0, 0));
+        if (mine && J.carry_dst) carry_pre = (float)J.carry_src[r];
     }
     if (J.pro) {
         // Fused layer_norm + token_shift prologue, computed ONCE per workgroup: thread t owns elements 8t..8t+7 (and
@@ -782,38 +782,40 @@ __device__ __forceinline__ void matvec_body_reg(const JobDev& J, unsigned char* 
             }
         }
         WRK_STAMP(J.dbg, 2);                    // weights arrived, dots done
+        // the RB reductions are independent chains; then lane rb finishes row rb, so the (long, dependent) epilogue of
+        // activation, rounding, residual, store runs ONCE per batch instead of once per row (0.25 us each, WRK_TIMING)
+        float mine_v = 0.0f;
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
-            if (ri0 + rb >= nrows) break;
             const float v = wave_sum(acc[rb]);
-            if (lane == 0) {
-                if (KS == 1) {
-                    const uint32_t r = row_of(ri0 + rb);
-                    float resv = res_pre[rb], carryv = carry_pre[rb];
-                    if (ri0 != 0) {     // rows beyond the first batch (more than 4 per wave): load on demand
-                        if (J.has_res) resv = dt_load(J.res, dt_index(J.res, r, 0, 0));
-                        if (J.carry_dst) carryv = (float)J.carry_src[r];
-                    }
-                    finish(r, v, resv, carryv);
-                } else part[(ri0 + rb) * 4 + wave] = v;
-            }
+            if (lane == (uint32_t)rb) mine_v = v;
         }
+        if (KS == 1) {
+            if (lane < (uint32_t)RB && ri0 + lane < nrows) {
+                const uint32_t r = row_of(ri0 + lane);
+                float resv = res_pre, carryv = carry_pre;
+                if (ri0 != 0) {     // rows beyond the first batch (more than 4 per wave): load on demand
+                    if (J.has_res) resv = dt_load(J.res, dt_index(J.res, r, 0, 0));
+                    if (J.carry_dst) carryv = (float)J.carry_src[r];
+                }
+                finish(r, mine_v, resv, carryv);
+            }
+        } else if (lane < (uint32_t)RB && ri0 + lane < nrows) part[(ri0 + lane) * 4 + wave] = mine_v;
     }
     if (KS == 4) {
         __syncthreads();
-        if (tid < nrows) finish(r0 + tid, (part[tid * 4] + part[tid * 4 + 1]) + (part[tid * 4 + 2] + part[tid * 4 + 3]), res_pre[0], carry_pre[0]);
+        if (tid < nrows) finish(r0 + tid, (part[tid * 4] + part[tid * 4 + 1]) + (part[tid * 4 + 2] + part[tid * 4 + 3]), res_pre, carry_pre);
     }
     WRK_STAMP(J.dbg, 3);                        // rows reduced and stored
     if (J.amax_val) {       // fused greedy sampling, stage 1 (uniform branch: every wave of the launch takes it)
         float* sv = (float*)(smem + 512);
         uint32_t* si = (uint32_t*)(smem + 528);
-        if (KS == 4) {      // candidates sit in lanes 0..nrows-1 of wave 0
+        // candidates sit in lanes 0..RB-1 of every wave (KS == 1) or lanes 0..nrows-1 of wave 0 (KS == 4)
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const float ov = __shfl_xor(best_v, o, WAVE);
-                const uint32_t oi = __shfl_xor(best_i, o, WAVE);
-                if (ov > best_v || (ov == best_v && oi < best_i)) { best_v = ov; best_i = oi; }
-            }
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best_v, o, WAVE);
+            const uint32_t oi = __shfl_xor(best_i, o, WAVE);
+            if (ov > best_v || (ov == best_v && oi < best_i)) { best_v = ov; best_i = oi; }
         }
         if (lane == 0) { sv[wave] = best_v; si[wave] = best_i; }
         __syncthreads();

@@ -34,9 +34,11 @@ struct wrk_v7_model {
     uint32_t* history = nullptr;    // generated tokens [steps][B] (device)
     size_t history_cap = 0;
 
+    // b: tokens (generate_greedy: sequences); mode: 0/1 for generate_greedy, or 16 + flag bits for wrk_v7_infer jobs
+    // (the analogue of the reference's cached RnnJob per RnnInfo, runtime/mod.rs:110-209); nh: header rows
     struct GraphKey {
-        const void* state; uint32_t b, mode;
-        bool operator<(const GraphKey& o) const { return std::tie(state, b, mode) < std::tie(o.state, o.b, o.mode); }
+        const void* state; uint32_t b, mode, nh = 0;
+        bool operator<(const GraphKey& o) const { return std::tie(state, b, mode, nh) < std::tie(o.state, o.b, o.mode, o.nh); }
     };
     std::map<GraphKey, wrk_program*> graphs;
 

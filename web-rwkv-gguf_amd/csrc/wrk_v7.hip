@@ -390,10 +390,41 @@ int32_t wrk_v7_infer(wrk_ctx* ctx, wrk_v7_model* m, wrk_v7_state* st, const uint
         rc = wrk_buf_write_raw(ctx, m->s.input, emb_rows, (size_t)T * D * 2);
         if (rc != WRK_OK) return rc;
     }
-    if (fused) rc = m->enqueue_fused_decode(st, T, NH, identity, tokens != nullptr, NH && argmax, false, cursors[0] & 0xff);
+    // The launches of a job depend only on its shape (token count, header rows, flags): cursors, tokens and header rows
+    // are device data.  Capture once per shape and replay (the reference caches the RnnJob of a repeated RnnInfo);
+    // a 128-token chunk of one sequence is ~1 400 small launches, which replay at graph rate.
+    auto enqueue_job = [&]() -> int32_t {
+        int32_t r;
+        if (fused) r = m->enqueue_fused_decode(st, T, NH, identity, tokens != nullptr, NH && argmax, false, cursors[0] & 0xff);
+        else {
+            r = m->enqueue_ops(st, T, NH, identity);
+            if (r == WRK_OK && NH && argmax) wrk::argmax_rows(ctx->stream, m->s.head_o, V, V, NH, m->s.argmax);
+        }
+        return r;
+    };
+    static const bool no_graph = [] { const char* e = getenv("WRK_NO_GRAPH"); return e && e[0] == '1'; }();
+    if (no_graph || ctx->capturing) rc = enqueue_job();
     else {
-        rc = m->enqueue_ops(st, T, NH, identity);
-        if (rc == WRK_OK && NH && argmax) wrk::argmax_rows(ctx->stream, m->s.head_o, V, V, NH, m->s.argmax);
+        const uint32_t flags = 16u | (fused ? 1u : 0u) | (identity ? 2u : 0u) | (tokens ? 4u : 0u) | ((NH && argmax) ? 8u : 0u) |
+                               (fused ? (cursors[0] & 0xffu) << 8 : 0u);
+        const wrk_v7_model::GraphKey key{st, T, flags, NH};
+        wrk_program* prog = nullptr;
+        auto it = m->graphs.find(key);
+        if (it != m->graphs.end()) prog = it->second;
+        else {
+            if (m->graphs.size() > 64) { WRK_HIP(ctx, hipStreamSynchronize(ctx->stream)); m->drop_graphs(); }    // bound the cache
+            rc = wrk_capture_begin(ctx);
+            if (rc != WRK_OK) return rc;
+            rc = enqueue_job();
+            wrk_program* p = nullptr;
+            const int32_t rc2 = wrk_capture_end(ctx, &p);
+            if (rc != WRK_OK) { if (p) wrk_program_destroy(p); return rc; }
+            if (rc2 != WRK_OK) return rc2;
+            prog = p;
+            m->graphs[key] = prog;
+        }
+        WRK_HIP(ctx, hipGraphLaunch(prog->exec, ctx->stream));
+        rc = WRK_OK;
     }
     if (rc != WRK_OK) return rc;
     WRK_LAUNCH_CHECK(ctx);
