@@ -82,8 +82,74 @@ def _q6k_blocks(rng, n_elem, std):
     return out.reshape(-1)
 
 
+def _q5k_blocks(rng, n_elem, std):
+    """Legal random Q5_K blocks (176 B: d, dmin, scales 12, qh 32, qs 128), w = d*sc*q - dmin*m ~ zero-mean."""
+    nb = n_elem // 256
+    out = np.empty((nb, 176), np.uint8)
+    d = np.float16(std / (47.5 * 9.23))
+    out[:, 0:2] = _f16b([d])
+    out[:, 2:4] = _f16b([np.float16(16.0) * d])
+    sc = rng.integers(32, 64, (nb, 8), dtype=np.uint8)
+    m = np.rint(sc.astype(np.float32) * (15.5 / 16.0)).astype(np.uint8)
+    s = np.zeros((nb, 12), np.uint8)
+    for j in range(4):
+        s[:, j] = (sc[:, j] & 63) | ((sc[:, j + 4] >> 4) << 6)
+        s[:, j + 4] = (m[:, j] & 63) | ((m[:, j + 4] >> 4) << 6)
+        s[:, j + 8] = (sc[:, j + 4] & 0xF) | ((m[:, j + 4] & 0xF) << 4)
+    out[:, 4:16] = s
+    out[:, 16:176] = rng.integers(0, 256, (nb, 160), dtype=np.uint8)
+    return out.reshape(-1)
+
+
+CONFIGS_V6 = {      # SURVEY section 8 cfg 4: L, D, F, V, time_mix rank, time_decay rank
+    "v6-tiny": (2, 256, 896, 512, 32, 64),
+    "v6-7B": (32, 4096, 14336, 65536, 64, 128),
+}
+
+
+def make_model_gguf_v6(name, seed=42):
+    """RWKV-6 "World" architecture, Q5_K_M-style: Q5_K matrices, Q6_K head, F16 embedding, F32 LoRA / vectors
+    (names: gguf.rs:1198-1251)."""
+    L, D, F, V, R, W = CONFIGS_V6[name]
+    rng = np.random.default_rng(seed)
+    tensors = []
+
+    def f32(nm, dims, vals):
+        tensors.append((nm, dims, 0, np.ascontiguousarray(vals, dtype="<f4").view(np.uint8).reshape(-1)))
+
+    def nrm(n, std):
+        return rng.standard_normal(n, dtype=np.float32) * np.float32(std)
+
+    tensors.append(("token_embd.weight", [D, V], 1, _f16b(nrm(V * D, 1.0))))
+    f32("token_embd_norm.weight", [D], 1 + nrm(D, 0.1)); f32("token_embd_norm.bias", [D], nrm(D, 0.05))
+    f32("output_norm.weight", [D], 1 + nrm(D, 0.1)); f32("output_norm.bias", [D], nrm(D, 0.05))
+    tensors.append(("output.weight", [D, V], 14, _q6k_blocks(rng, V * D, 1.0 / np.sqrt(D))))
+    for l in range(L):
+        p = f"blk.{l}."
+        for nm in ("attn_norm", "attn_norm_2", "attn_ln_x"):
+            f32(p + nm + ".weight", [D], 1 + nrm(D, 0.1)); f32(p + nm + ".bias", [D], nrm(D, 0.05))
+        f32(p + "attn_time_decay", [D], rng.random(D, dtype=np.float32) * 3.5 - 3.0)
+        f32(p + "attn_time_first", [64, D // 64], nrm(D, 0.3))
+        for nm in ("x", "w", "k", "v", "r", "g"):
+            f32(p + f"attn_time_mix_{nm}", [D], rng.random(D, dtype=np.float32))
+        f32(p + "attn_time_mix_w1", [D, 5 * R], nrm(5 * R * D, 1.0 / np.sqrt(D)))
+        f32(p + "attn_time_mix_w2", [R, D, 5], nrm(5 * D * R, 0.3 / np.sqrt(R)))
+        f32(p + "attn_time_decay_w1", [D, W], nrm(W * D, 1.0 / np.sqrt(D)))
+        f32(p + "attn_time_decay_w2", [W, D], nrm(D * W, 0.5 / np.sqrt(W)))
+        for nm in ("k", "v", "r", "g", "output"):
+            tensors.append((p + f"attn_{nm}.weight", [D, D], 13, _q5k_blocks(rng, D * D, (0.5 if nm == "k" else 1.0) / np.sqrt(D))))
+        f32(p + "ffn_time_mix_k", [D], rng.random(D, dtype=np.float32)); f32(p + "ffn_time_mix_r", [D], rng.random(D, dtype=np.float32))
+        tensors.append((p + "ffn_k.weight", [D, F], 13, _q5k_blocks(rng, F * D, 1.0 / np.sqrt(D))))
+        tensors.append((p + "ffn_v.weight", [F, D], 13, _q5k_blocks(rng, D * F, 0.5 / np.sqrt(F))))
+        tensors.append((p + "ffn_r.weight", [D, D], 13, _q5k_blocks(rng, D * D, 1.0 / np.sqrt(D))))
+    meta = [("general.architecture", 8, "rwkv6"), ("general.alignment", 4, 32), ("rwkv6.wkv.head_size", 4, 64),
+            ("rwkv6.block_count", 4, L), ("rwkv6.embedding_length", 4, D), ("rwkv6.feed_forward_length", 4, F)]
+    return _write_gguf(tensors, meta)
+
+
 def make_model_gguf(name, seed=42):
-    import struct
+    if name in CONFIGS_V6:
+        return make_model_gguf_v6(name, seed)
     L, D, F, V, rw, ra, rv, rg = CONFIGS[name]
     rng = np.random.default_rng(seed)
     tensors = []        # (name, dims, type_id, raw)
@@ -117,12 +183,18 @@ def make_model_gguf(name, seed=42):
         tensors.append((p + "channel_mix_key.weight", [D, F], 12, _q4k_blocks(rng, F * D, 1.0 / np.sqrt(D))))
         tensors.append((p + "channel_mix_value.weight", [F, D], 12, _q4k_blocks(rng, D * F, 0.5 / np.sqrt(F))))
 
+    meta = [("general.architecture", 8, "rwkv7"), ("general.alignment", 4, 32), ("rwkv7.wkv.head_size", 4, 64),
+            ("rwkv7.block_count", 4, L), ("rwkv7.embedding_length", 4, D), ("rwkv7.feed_forward_length", 4, F)]
+    return _write_gguf(tensors, meta)
+
+
+def _write_gguf(tensors, meta):
+    import struct
+
     def wstr(s):
         b = s.encode()
         return struct.pack("<Q", len(b)) + b
 
-    meta = [("general.architecture", 8, "rwkv7"), ("general.alignment", 4, 32), ("rwkv7.wkv.head_size", 4, 64),
-            ("rwkv7.block_count", 4, L), ("rwkv7.embedding_length", 4, D), ("rwkv7.feed_forward_length", 4, F)]
     head = bytearray(struct.pack("<IIQQ", 0x46554747, 3, len(tensors), len(meta)))
     for k, t, v in meta:
         head += wstr(k) + struct.pack("<I", t) + (wstr(v) if t == 8 else struct.pack("<I", v))
@@ -155,7 +227,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=32)
-    ap.add_argument("--model", default="1.5B", choices=sorted(CONFIGS))
+    ap.add_argument("--model", default="1.5B", choices=sorted(CONFIGS) + sorted(CONFIGS_V6))
     ap.add_argument("--batch", type=int, default=1, help="independent streams per GPU")
     ap.add_argument("--mode", type=int, default=1, help="1 = fused decode kernels, 0 = one kernel per reference op")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -210,8 +282,10 @@ def main():
             "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"RWKV-7 World {args.model} Q4_K_M (Q4_K matrices, Q6_K head, F16 LoRA) batch={B} greedy decode, "
-                                   f"{'fused kernels' if args.mode == 1 else 'one kernel per reference op'} under hipGraph",
+            "config": {"workload": (f"RWKV-6 World {args.model[3:]} Q5_K_M (Q5_K matrices, Q6_K head, F16 LoRA) batch={B} greedy decode, "
+                                    if args.model in CONFIGS_V6 else
+                                    f"RWKV-7 World {args.model} Q4_K_M (Q4_K matrices, Q6_K head, F16 LoRA) batch={B} greedy decode, ") +
+                                   f"{'fused kernels' if args.mode == 1 and args.model not in CONFIGS_V6 else 'one kernel per reference op'} under hipGraph",
                        "streams_per_gpu": B, "parallelism": f"replicas x{world}" if world > 1 else "single"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.model, B, args.mode),
@@ -219,7 +293,7 @@ def main():
             "wall_ms_per_step_incl_host": round(wall_ms / args.steps, 5), "load_seconds": round(load_s, 1),
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(gg, first[0])
+            out["cpu_baseline"] = cpu_baseline(gg, first[0]) if args.model not in CONFIGS_V6 else None     # the C port is RWKV-7 only
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

@@ -178,3 +178,26 @@ def test_golden_logits(ctx):
     toks, _ = rt.generate_greedy([int(g["logits_inline"][0].argmax())], len(g["greedy_inline"]), mode=1)
     assert toks[:, 0].tolist() == g["greedy_inline"].tolist()
     rt.close()
+
+
+def test_empty_and_maximum_chunks(ctx):
+    """Edge sizes of one job: no tokens at all (v7.rs:626-635 returns an empty output), the longest chunk a cursor
+    can describe (255 tokens, `Cursor::pack` keeps `len` in 8 bits, tensor/mod.rs:53-60) with EVERY row's logits
+    (RnnOption::Full -> header rows = all tokens; exercises the tiled prefill GEMM and the chunk WKV kernel inside a
+    whole model), and one token more (rejected, not truncated)."""
+    rt, oracle = build(ctx, "tiny", wrk.WEIGHTS_INLINE, 1)
+    V = rt.info.num_vocab
+    assert rt.infer_raw([], [], []).shape == (0, V)                     # T = 0: no-op
+    toks = synth.tokens(13, "long", 255, V)
+    got = rt.infer_raw(toks, stack_cursors([255]), list(range(255)))
+    want = oracle.infer_chunk([toks], list(range(255)))
+    assert got.shape == want.shape == (255, V)
+    d = np.abs(got - want)
+    # 255 tokens of recurrence: the f16-flip noise floor grows with depth (DESIGN.md "Tolerances"); rows near the start
+    # are tight, the bound below is for the whole chunk
+    assert d[:32].max() <= LOGIT_TOL and d.max() <= 4 * LOGIT_TOL and d.mean() <= 2 * LOGIT_MEAN_TOL, (d[:32].max(), d.max(), d.mean())
+    assert (got.argmax(axis=1) == want.argmax(axis=1)).mean() >= 0.99
+    assert_state_close(rt.state_back(0), oracle.state.back(0))
+    with pytest.raises(wrk.WrkError):
+        rt.infer(wrk.RnnInput([synth.tokens(1, "x", 300, V)], 512))     # 300 tokens of one sequence in one chunk
+    rt.close()

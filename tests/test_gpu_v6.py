@@ -135,3 +135,30 @@ def test_v6_prefill_then_greedy_decode(ctx, name, weights, kw):
         d = np.abs(rt.state_back(b) - oracle.state[:, b])
         assert d.max() <= 3e-2 * max(1.0, float(np.abs(oracle.state).max())) and d.mean() <= max(1e-3, tol_mean)
     rt.close()
+
+
+@pytest.mark.parametrize("B", [1, 3, 5])
+@pytest.mark.parametrize("mat", ["Q5_K", "Q8_0"])
+def test_v6_fused_decode_matches_op_by_op_and_oracle(ctx, B, mat):
+    """The 7-launch fused decode (mode 1: LN prologues, v6_mix / v6_head kernels, gated epilogue; B = 1 register-input
+    matvecs, B = 3 multi-token matvec, B = 5 MFMA) against the one-kernel-per-op path (mode 0) and the oracle."""
+    cfg = synth.V6_CONFIGS["small"]
+    data = synth.make_v6_gguf(cfg, 11, mat=mat)
+    first = [(7 + 31 * b) % (cfg.num_vocab - 1) for b in range(B)]
+    rt1 = wrk.Runtime(ctx, wrk.GgufReader(data), num_batch=B, weights=wrk.WEIGHTS_INLINE)
+    rt0 = wrk.Runtime(ctx, wrk.GgufReader(data), num_batch=B, weights=wrk.WEIGHTS_INLINE)
+    t1, _, l1 = rt1.generate_greedy(first, 10, mode=1, want_logits=True)
+    t0, _, l0 = rt0.generate_greedy(first, 10, mode=0, want_logits=True)
+    assert t1.tolist() == t0.tolist()
+    assert np.abs(l1 - l0).max() <= 3e-2 and np.abs(l1 - l0).mean() <= 6e-3
+    for b in range(B):
+        d = np.abs(rt1.state_back(b) - rt0.state_back(b))
+        assert d.max() <= 3e-2 * max(1.0, float(np.abs(rt0.state_back(b)).max())) and d.mean() <= 2e-3
+    model = O6.build_v6(ogguf.GgufReader(data), weights_f16=False)
+    oracle = O6.V6Runtime(model, B, act_f16=True)
+    toks = list(first)
+    for step in range(10):
+        ol = oracle.infer_chunk([[t] for t in toks], list(range(B)))
+        toks = [int(ol[b].argmax()) for b in range(B)]
+        assert t1[step].tolist() == toks, step
+    rt1.close(); rt0.close()

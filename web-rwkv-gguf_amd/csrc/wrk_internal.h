@@ -173,6 +173,7 @@ struct MatJob {
     void* ln_out = nullptr;         // f16 [K]: LN(in), published by the first workgroup of the job
     const void* carry_src = nullptr;    // epilogue: carry_dst[row] = carry_src[row]
     float* carry_dst = nullptr;
+    const void* gate = nullptr;         // f16 [M]: out = round(sigmoid(gate[row]) * round(act(W.x)))  (channel_mix.wgsl:104-106, RWKV-6), before the residual
     unsigned long long* dbg = nullptr;  // WRK_TIMING=1: 16 device timestamps of this launch (first and last workgroup)
 };
 uint32_t matvec_num_wg(const MatJob* jobs, int njobs, int num_cu, uint32_t* rows_per_wg);

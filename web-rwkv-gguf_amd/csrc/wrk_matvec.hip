@@ -241,6 +241,7 @@ struct JobDev {
     // optional fused shift-state carry in the epilogue: carry_dst[row] = carry_src[row] (channel_mix_v7's state write)
     const f16* carry_src;
     float* carry_dst;
+    const f16* gate;
     unsigned long long* dbg;
 };
 
@@ -683,12 +684,13 @@ __device__ __forceinline__ void matvec_body_reg(const JobDev& J, unsigned char* 
     XRegs x[XI];
     // epilogue operands: the thread that will finish a row fetches that row's residual / carry value now.
     // KS == 1: lane rb (< RB) of a wave finishes the wave's rb-th row; KS == 4: thread tid finishes row r0 + tid.
-    float res_pre = 0.0f, carry_pre = 0.0f;
+    float res_pre = 0.0f, carry_pre = 0.0f, gate_pre = 0.0f;
     {
         const uint32_t r = KS == 1 ? row_of(lane) : r0 + tid;
         const bool mine = KS == 1 ? (lane < (uint32_t)RB && lane < nrows) : tid < nrows;
         if (mine && J.has_res) res_pre = dt_load(J.res, dt_index(J.res, r, 0, 0));
         if (mine && J.carry_dst) carry_pre = (float)J.carry_src[r];
+        if (mine && J.gate) gate_pre = (float)J.gate[r];
     }
     if (J.pro) {
         // Fused layer_norm + token_shift prologue, computed ONCE per workgroup: thread t owns elements 8t..8t+7 (and
@@ -762,8 +764,9 @@ __device__ __forceinline__ void matvec_body_reg(const JobDev& J, unsigned char* 
     float* part = (float*)smem;                 // KS == 4: [32 rows][4 waves]
     float best_v = -3.0e38f;
     uint32_t best_i = 0xffffffffu;
-    auto finish = [&](uint32_t r, float v, float resv, float carryv) {    // activation, fused residual, store, running arg-max
+    auto finish = [&](uint32_t r, float v, float resv, float carryv, float gatev) {    // activation, fused residual, store, running arg-max
         float o = act_apply(J.act, v);
+        if (J.gate) o = act_sigmoid(gatev) * dt_round(J.out, o);
         if (J.has_res) o = dt_round(J.out, o) + resv;
         dt_store(J.out, dt_index(J.out, r, 0, 0), o);
         if (J.carry_dst) J.carry_dst[r] = carryv;
@@ -793,18 +796,19 @@ __device__ __forceinline__ void matvec_body_reg(const JobDev& J, unsigned char* 
         if (KS == 1) {
             if (lane < (uint32_t)RB && ri0 + lane < nrows) {
                 const uint32_t r = row_of(ri0 + lane);
-                float resv = res_pre, carryv = carry_pre;
+                float resv = res_pre, carryv = carry_pre, gatev = gate_pre;
                 if (ri0 != 0) {     // rows beyond the first batch (more than 4 per wave): load on demand
                     if (J.has_res) resv = dt_load(J.res, dt_index(J.res, r, 0, 0));
                     if (J.carry_dst) carryv = (float)J.carry_src[r];
+                    if (J.gate) gatev = (float)J.gate[r];
                 }
-                finish(r, mine_v, resv, carryv);
+                finish(r, mine_v, resv, carryv, gatev);
             }
         } else if (lane < (uint32_t)RB && ri0 + lane < nrows) part[(ri0 + lane) * 4 + wave] = mine_v;
     }
     if (KS == 4) {
         __syncthreads();
-        if (tid < nrows) finish(r0 + tid, (part[tid * 4] + part[tid * 4 + 1]) + (part[tid * 4 + 2] + part[tid * 4 + 3]), res_pre, carry_pre);
+        if (tid < nrows) finish(r0 + tid, (part[tid * 4] + part[tid * 4 + 1]) + (part[tid * 4 + 2] + part[tid * 4 + 3]), res_pre, carry_pre, gate_pre);
     }
     WRK_STAMP(J.dbg, 3);                        // rows reduced and stored
     if (J.amax_val) {       // fused greedy sampling, stage 1 (uniform branch: every wave of the launch takes it)
@@ -953,7 +957,7 @@ static int launch_matvec(hipStream_t s, const MatvecParams& P, uint32_t total_wg
     }
     matvec_fn fn = nullptr;
     bool needs_reg = false;     // fused prologue / state carry exist only in the register-input decode kernel
-    for (int j = 0; j < P.njobs; ++j) needs_reg = needs_reg || P.jobs[j].pro || P.jobs[j].carry_dst;
+    for (int j = 0; j < P.njobs; ++j) needs_reg = needs_reg || P.jobs[j].pro || P.jobs[j].carry_dst || P.jobs[j].gate;
     if (NB == 1 && tok_groups == 1 && nquant <= 1 && !mixed_r16) {
         fn = pick_reg(P, nquant ? quant : -1, has_f16, r16);
         if (fn) {
@@ -1023,7 +1027,7 @@ int matvec(hipStream_t s, const MatJob* jobs, int njobs, int num_cu, bool dry_ru
         d.amax_val = jobs[j].amax_val; d.amax_idx = jobs[j].amax_idx;
         d.pro = jobs[j].pro; d.pro_eps = jobs[j].pro_eps; d.ln_w = (const f16*)jobs[j].ln_w; d.ln_b = (const f16*)jobs[j].ln_b;
         d.mixw = (const f16*)jobs[j].mixw; d.prev = jobs[j].prev; d.ln_out = (f16*)jobs[j].ln_out;
-        d.carry_src = (const f16*)jobs[j].carry_src; d.carry_dst = jobs[j].carry_dst; d.dbg = jobs[j].dbg;
+        d.carry_src = (const f16*)jobs[j].carry_src; d.carry_dst = jobs[j].carry_dst; d.gate = (const f16*)jobs[j].gate; d.dbg = jobs[j].dbg;
         wg += (jobs[j].m + d.rows_per_wg - 1) / d.rows_per_wg;
     }
     const uint32_t kpad = (kmax + 15u) & ~15u;

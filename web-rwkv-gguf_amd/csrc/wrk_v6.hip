@@ -25,12 +25,13 @@ struct wrk_v6_model {
     V6Scratch s{};
     uint32_t* history = nullptr;
     size_t history_cap = 0;
-    std::map<std::pair<const void*, uint32_t>, wrk_program*> graphs;
+    std::map<std::tuple<const void*, uint32_t, uint32_t>, wrk_program*> graphs;      // (state, sequences, mode)
 
     void drop_graphs() { for (auto& kv : graphs) wrk_program_destroy(kv.second); graphs.clear(); }
     int32_t ensure_scratch(uint32_t T, uint32_t NH);
     int32_t ensure_history(size_t n);
     int32_t enqueue_ops(wrk_v7_state* st, uint32_t T, uint32_t NH, bool identity);
+    int32_t enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_t NH, bool identity, uint32_t batch0);
 };
 
 static inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -166,6 +167,311 @@ int32_t wrk_v6_model::enqueue_ops(wrk_v7_state* st, uint32_t T, uint32_t NH, boo
     return WRK_OK;
 }
 
+// ====================================================================== fused RWKV-6 decode (one token per sequence)
+// 7 launches per layer instead of ~45 (v6.rs:701-958 restated stage by stage; every f16 store of the reference's
+// Runtime<f16> buffers is reproduced as an explicit rounding):
+//   K1  LN1 + token_shift(time_mix_x) [prologue] -> time_mix_w1 matvec (tanh)                       -> tmx [5R]
+//   K2  v6_mix_kernel: five LoRA up-projections + add(time_mix) + 5-way data-dependent token shift   -> sx5 [5][D]
+//   K3  one launch: w_k, w_v, w_r (f32 out), w_g, time_decay_w1 (tanh), each on its own shifted input
+//   K4  v6_head_kernel: decay LoRA up + stable_exp, WKV6 with the state in registers, group norm, SiLU gate, state carry
+//   K5  w_o + residual
+//   K6  LN2 + two token shifts [prologue] -> ffn key (relu^2), ffn receptance
+//   K7  ffn value, sigmoid(receptance) gate, residual, ffn shift-state carry  [epilogue]
+namespace wrk {
+
+struct V6MixParams {
+    uint32_t d, r;                          // D, time_mix rank R
+    const f16* w2[5]; uint32_t w2_rb;       // five F16 matrices [D][R] (device rows of w2_rb bytes)
+    const f16* tmx;                         // [T][5R] tanh(time_mix_w1 . shifted x)
+    const f16* time_mix;                    // [5][D]
+    const f16* x_ln;                        // [T][D]  LN1(x)
+    const float* state;                     // layer state base; att shift row of batch b at state[b * (S+2) * D]
+    const uint32_t* cursors;
+    uint32_t batch1;                        // batch + 1 when the host knows it, else 0
+    f16* sx5;                               // [5][T][D]
+    uint32_t T;
+};
+
+// thread (row = tid >> 2, part = tid & 3): 4 lanes share a channel's five R-long dot products
+__global__ void __launch_bounds__(256) v6_mix_kernel(const V6MixParams P) {
+    const uint32_t tid = threadIdx.x, row = tid >> 2, part = tid & 3u, t = blockIdx.y;
+    const uint32_t c = blockIdx.x * 64 + row, D = P.d, R = P.r;
+    if (c >= D) return;
+    const f16* aux = P.tmx + (size_t)t * 5 * R;
+    f16x8 w[5][4], xx[5][4];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const uint32_t k = part * 8 + 32 * n;
+            if (k < R) { w[i][n] = *(const f16x8*)((const uint8_t*)P.w2[i] + (size_t)c * P.w2_rb + k * 2); xx[i][n] = *(const f16x8*)(aux + i * R + k); }
+        }
+    const float xl = (float)P.x_ln[(size_t)t * D + c];
+    const uint32_t batch = P.batch1 ? P.batch1 - 1 : (P.cursors[t] & 0xffu);
+    const float prev = P.state[(size_t)batch * 66 * D + c];
+    float tmv[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) tmv[i] = (float)P.time_mix[(size_t)i * D + c];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            if (part * 8 + 32 * n < R) {
+                acc = __builtin_amdgcn_fdot2(__builtin_shufflevector(w[i][n], w[i][n], 0, 1), __builtin_shufflevector(xx[i][n], xx[i][n], 0, 1), acc, false);
+                acc = __builtin_amdgcn_fdot2(__builtin_shufflevector(w[i][n], w[i][n], 2, 3), __builtin_shufflevector(xx[i][n], xx[i][n], 2, 3), acc, false);
+                acc = __builtin_amdgcn_fdot2(__builtin_shufflevector(w[i][n], w[i][n], 4, 5), __builtin_shufflevector(xx[i][n], xx[i][n], 4, 5), acc, false);
+                acc = __builtin_amdgcn_fdot2(__builtin_shufflevector(w[i][n], w[i][n], 6, 7), __builtin_shufflevector(xx[i][n], xx[i][n], 6, 7), acc, false);
+            }
+        }
+        acc += __shfl_xor(acc, 1, WAVE);
+        acc += __shfl_xor(acc, 2, WAVE);
+        if (part == 0) {
+            const float f = r16(r16(acc) + tmv[i]);                                        // matmul (f16 store) + add(time_mix)
+            P.sx5[((size_t)i * P.T + t) * D + c] = (f16)wgsl_mix(xl, prev, f);             // token_shift(.., reversed)
+        }
+    }
+}
+
+struct V6HeadParams {
+    uint32_t d, w;                          // D, time_decay rank W
+    const f16* dw2; uint32_t dw2_rb;        // time_decay_w2 F16 [D][W]
+    const f16* att_w;                       // [T][W] tanh(time_decay_w1 . sx_w)
+    const f16* time_decay;                  // [D]
+    const float* u;                         // time_first f32 [D]
+    const float *k, *v, *r;                 // [T][D] f32
+    const f16* g;                           // [T][D]
+    const f16 *gn_w, *gn_b;
+    float* state;                           // layer state base
+    const uint32_t* cursors;
+    uint32_t batch1;
+    const f16* shift_src;                   // LN1(x) [T][D]: becomes the att shift state
+    f16* out;                               // [T][D]
+    float gn_eps;
+};
+
+// One workgroup per (head, token).  Thread (i = tid >> 2, part = tid & 3) owns S[16 part .. +15][i] (quad layout: the
+// reduction over j is in-register + two quad shuffles).  The 64 decay values of the head are produced cooperatively
+// (thread (row, part) = one quarter of a W-long dot product) and shared through LDS with k, r, u.
+__global__ void __launch_bounds__(256) v6_head_kernel(const V6HeadParams P) {
+    constexpr int S = 64;
+    __shared__ __attribute__((aligned(16))) float sh_w[S], sh_k[S], sh_r[S], sh_u[S], sh_y[S];
+    const uint32_t head = blockIdx.x, t = blockIdx.y, tid = threadIdx.x, D = P.d, W = P.w;
+    const uint32_t c0 = head * S, row = tid >> 2, part = tid & 3u, i = row, ch = c0 + row;
+    // decay LoRA up-projection of channel ch (a key channel j = row of this head)
+    f16x8 w[4], xx[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const uint32_t k = part * 8 + 32 * n;
+        if (k < W) { w[n] = *(const f16x8*)((const uint8_t*)P.dw2 + (size_t)ch * P.dw2_rb + k * 2); xx[n] = *(const f16x8*)(P.att_w + (size_t)t * W + k); }
+    }
+    const float td0 = (float)P.time_decay[ch];
+    const float kj = P.k[(size_t)t * D + ch], rj = P.r[(size_t)t * D + ch], uj = P.u[ch];
+    const float vv = P.v[(size_t)t * D + ch];                   // as value column i = row
+    const float gg = (float)P.g[(size_t)t * D + ch];
+    const float gnw = (float)P.gn_w[ch], gnb = (float)P.gn_b[ch];
+    float shift = 0.0f;
+    if (part == 1) shift = (float)P.shift_src[(size_t)t * D + ch];
+    const uint32_t batch = P.batch1 ? P.batch1 - 1 : (P.cursors[t] & 0xffu);
+    float* st = P.state + ((size_t)batch * (S + 2) + 1) * D + c0 + i;
+    float Sreg[16];
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) Sreg[jj] = st[(size_t)(part * 16 + jj) * D];
+    float acc = 0.0f;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        if (part * 8 + 32 * n < W) {
+            acc = __builtin_amdgcn_fdot2(__builtin_shufflevector(w[n], w[n], 0, 1), __builtin_shufflevector(xx[n], xx[n], 0, 1), acc, false);
+            acc = __builtin_amdgcn_fdot2(__builtin_shufflevector(w[n], w[n], 2, 3), __builtin_shufflevector(xx[n], xx[n], 2, 3), acc, false);
+            acc = __builtin_amdgcn_fdot2(__builtin_shufflevector(w[n], w[n], 4, 5), __builtin_shufflevector(xx[n], xx[n], 4, 5), acc, false);
+            acc = __builtin_amdgcn_fdot2(__builtin_shufflevector(w[n], w[n], 6, 7), __builtin_shufflevector(xx[n], xx[n], 6, 7), acc, false);
+        }
+    }
+    acc += __shfl_xor(acc, 1, WAVE);
+    acc += __shfl_xor(acc, 2, WAVE);
+    if (part == 0) {
+        // time_decay buffer is f32: matmul result unrounded, + time_decay, then activate(StableExp) = exp(-exp(x))
+        sh_w[row] = __expf(-__expf(acc + td0));
+        sh_k[row] = kj; sh_r[row] = rj; sh_u[row] = uj;
+    }
+    if (part == 1) P.state[(size_t)batch * (S + 2) * D + ch] = shift;          // att shift-state carry
+    __syncthreads();
+    float y = 0.0f;
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+        const int j = part * 16 + jj;
+        const float kv = sh_k[j] * vv;
+        y += sh_r[j] * __builtin_fmaf(sh_u[j], kv, Sreg[jj]);
+        const float sn = __builtin_fmaf(sh_w[j], Sreg[jj], kv);
+        st[(size_t)j * D] = sn;
+    }
+    y = (y + __shfl_xor(y, 1, WAVE));
+    y = (y + __shfl_xor(y, 2, WAVE));
+    if (part == 0) sh_y[i] = r16(y);                                            // aux_x (f16 store)
+    __syncthreads();
+    if (tid < S) {      // group norm over the head, SiLU gate: thread = column
+        const float yv = sh_y[tid];
+        const float mean = wave_sum(yv) * (1.0f / S);
+        const float dl = yv - mean;
+        const float var = wave_sum(dl * dl) * (1.0f / S) + P.gn_eps;
+        // the per-column operands were loaded by thread (row = tid, part 0) = thread 4 * tid: re-load for this mapping
+        const uint32_t c = c0 + tid;
+        const float o = r16(__builtin_fmaf(dl * (1.0f / sqrtf(var)), (float)P.gn_w[c], (float)P.gn_b[c]));
+        const float gv = (float)P.g[(size_t)t * D + c];
+        P.out[(size_t)t * D + c] = (f16)((gv / (1.0f + __expf(-gv))) * o);       // mul_activate(att_g Silu, att_x)
+    }
+    (void)gg; (void)gnw; (void)gnb;
+}
+
+}  // namespace wrk
+
+static wrk::MatJob job6(const wrk_matrix* m, DTensor in, DTensor out, uint32_t act) {
+    return wrk::MatJob{m->data, m->aux, m->kind, m->flags, m->k, m->m, (uint32_t)m->row_bytes, in, out, act, 0};
+}
+
+// One decode step for T stacked tokens, each its own sequence.  Returns WRK_E_UNSUPPORTED (without launching anything)
+// when the model's shapes are outside the fused kernels' range; callers then use enqueue_ops.
+int32_t wrk_v6_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_t NH, bool identity, uint32_t batch0) {
+    hipStream_t q = ctx->stream;
+    const uint32_t D = d.num_emb, F = d.num_hidden, H = d.num_head, S = 64, V = d.num_vocab, R = d.time_mix, W = d.time_decay;
+    if (R > 128 || W > 128 || (R & 7u) || (W & 7u) || (D & 7u) || D > 8192) return WRK_E_UNSUPPORTED;
+    for (auto& L : layers) {
+        const wrk_matrix* f16m[] = {L.time_mix_w2[0], L.time_mix_w2[1], L.time_mix_w2[2], L.time_mix_w2[3], L.time_mix_w2[4], L.time_decay_w2};
+        for (const wrk_matrix* m : f16m) if (m->kind != WRK_MAT_F16) return WRK_E_UNSUPPORTED;
+        if (L.time_mix_w2[1]->row_bytes != L.time_mix_w2[0]->row_bytes) return WRK_E_UNSUPPORTED;
+    }
+    auto vec = [&](void* p, uint32_t c = 0, uint32_t dt = WRK_F16) { return make_dense(p, dt, c ? c : D, T); };
+    auto run_jobs = [&](wrk::MatJob* jobs, int n) -> int {
+        if (T >= wrk::gemm_min_tokens()) {
+            if (wrk::matmul_mfma_multi(q, jobs, n, ctx->num_cu) == 0) return 0;
+            for (int i = 0; i < n; ++i) {
+                int rc = wrk::matmul_mfma(q, jobs[i], ctx->num_cu);
+                if (rc == -2) rc = wrk::matvec(q, &jobs[i], 1, ctx->num_cu);
+                if (rc != 0) return rc;
+            }
+            return 0;
+        }
+        return wrk::matvec(q, jobs, n, ctx->num_cu);
+    };
+#define LNMIX(P, n) do { if (wrk::ln_mix(q, P, n) != 0) return wrk_fail(ctx, WRK_E_UNSUPPORTED, "ln_mix shape"); } while (0)
+    {   // embedding rows (already gathered into s.input) -> LN0 -> x
+        wrk::LnMixParams P{};
+        P.src = (const f16*)s.input; P.ln_w = (const f16*)d.ln0_w->ptr; P.ln_b = (const f16*)d.ln0_b->ptr; P.eps = LN_EPS;
+        P.d = D; P.nmix = 0; P.ln_out = (f16*)s.x;
+        LNMIX(P, T);
+    }
+    const size_t sxs = (size_t)T * D;                                   // elements between the five shifted inputs
+    for (uint32_t li = 0; li < d.num_layer; ++li) {
+        const wrk_v6_layer_desc& L = layers[li];
+        float* lst = st->layer_ptr(li);
+        float* row0 = lst + (size_t)batch0 * (S + 2) * D;               // att shift state (T == 1: of that sequence)
+        float* rowf = lst + ((size_t)batch0 * (S + 2) + (S + 1)) * D;   // ffn shift state
+        // per layer: can the two LN prologues / the gated epilogue ride the register-input matvec kernels?
+        bool single = (T == 1) && D <= 4096;
+        if (single) {
+            wrk::MatJob a = job6(L.time_mix_w1, vec(s.x), vec(s.tmx, 5 * R), 0); a.pro = 1;
+            wrk::MatJob b[2] = {job6(L.ffn_w_k, vec(s.x), vec(s.ffn_k, F), 0), job6(L.ffn_w_r, vec(s.x), vec(s.ffn_r), 0)};
+            b[0].pro = b[1].pro = 1;
+            wrk::MatJob c = job6(L.ffn_w_v, vec(s.ffn_k, F), vec(s.x), 0); c.gate = s.ffn_r; c.carry_dst = (float*)s.x;
+            single = wrk::matvec(q, &a, 1, ctx->num_cu, true) == 0 && wrk::matvec(q, b, 2, ctx->num_cu, true) == 0 &&
+                     wrk::matvec(q, &c, 1, ctx->num_cu, true) == 0;
+        }
+        {   // K1
+            wrk::MatJob j = job6(L.time_mix_w1, vec(s.att_xx), vec(s.tmx, 5 * R), WRK_ACT_TANH);
+            if (single) {
+                j.in = vec(s.x);
+                j.pro = 1; j.pro_eps = LN_EPS; j.ln_w = L.ln1_w->ptr; j.ln_b = L.ln1_b->ptr; j.mixw = L.time_mix_x->ptr; j.prev = row0;
+                j.ln_out = s.att_x;
+            } else {
+                wrk::LnMixParams P{};
+                P.src = (const f16*)s.x; P.ln_w = (const f16*)L.ln1_w->ptr; P.ln_b = (const f16*)L.ln1_b->ptr; P.eps = LN_EPS;
+                P.d = D; P.nmix = 1; P.mix[0] = (const f16*)L.time_mix_x->ptr; P.out[0] = (f16*)s.att_xx; P.ln_out = (f16*)s.att_x;
+                P.state_row = lst; P.state_stride = (size_t)(S + 2) * D; P.cursors = s.cursors; P.no_carry = 1;
+                LNMIX(P, T);
+            }
+            if (run_jobs(&j, 1) != 0) return wrk_fail(ctx, WRK_E_ARG, "fused V6 K1 rejected");
+        }
+        {   // K2
+            wrk::V6MixParams P{};
+            P.d = D; P.r = R; P.w2_rb = (uint32_t)L.time_mix_w2[0]->row_bytes;
+            for (int i = 0; i < 5; ++i) P.w2[i] = (const f16*)L.time_mix_w2[i]->data;
+            P.tmx = (const f16*)s.tmx; P.time_mix = (const f16*)L.time_mix->ptr; P.x_ln = (const f16*)s.att_x;
+            P.state = lst; P.cursors = s.cursors; P.batch1 = single ? batch0 + 1 : 0; P.sx5 = (f16*)s.att_sx; P.T = T;
+            wrk::v6_mix_kernel<<<dim3((D + 63) / 64, T), 256, 0, q>>>(P);
+        }
+        {   // K3: order of the shifted inputs is w, k, v, r, g (v6.rs:1054-1071)
+            f16* sx = (f16*)s.att_sx;
+            wrk::MatJob jobs[5] = {job6(L.w_k, vec(sx + 1 * sxs), vec(s.att_k, 0, WRK_F32), WRK_ACT_NONE),
+                                   job6(L.w_v, vec(sx + 2 * sxs), vec(s.att_v, 0, WRK_F32), WRK_ACT_NONE),
+                                   job6(L.w_r, vec(sx + 3 * sxs), vec(s.att_r, 0, WRK_F32), WRK_ACT_NONE),
+                                   job6(L.w_g, vec(sx + 4 * sxs), vec(s.att_g), WRK_ACT_NONE),
+                                   job6(L.time_decay_w1, vec(sx + 0 * sxs), vec(s.att_w, W), WRK_ACT_TANH)};
+            if (run_jobs(jobs, 5) != 0) return wrk_fail(ctx, WRK_E_ARG, "fused V6 K3 rejected");
+        }
+        {   // K4
+            wrk::V6HeadParams P{};
+            P.d = D; P.w = W; P.dw2 = (const f16*)L.time_decay_w2->data; P.dw2_rb = (uint32_t)L.time_decay_w2->row_bytes;
+            P.att_w = (const f16*)s.att_w; P.time_decay = (const f16*)L.time_decay->ptr; P.u = (const float*)L.time_first->ptr;
+            P.k = s.att_k; P.v = s.att_v; P.r = s.att_r; P.g = (const f16*)s.att_g;
+            P.gn_w = (const f16*)L.gn_w->ptr; P.gn_b = (const f16*)L.gn_b->ptr;
+            P.state = lst; P.cursors = s.cursors; P.batch1 = single ? batch0 + 1 : 0;
+            P.shift_src = (const f16*)s.att_x; P.out = (f16*)s.aux_x; P.gn_eps = GN_EPS;
+            wrk::v6_head_kernel<<<dim3(H, T), 256, 0, q>>>(P);
+        }
+        {   // K5: x += W_o . att
+            wrk::MatJob j = job6(L.w_o, vec(s.aux_x), vec(s.x), WRK_ACT_NONE);
+            j.has_res = 1; j.res = vec(s.x);
+            if (run_jobs(&j, 1) != 0) return wrk_fail(ctx, WRK_E_ARG, "fused V6 K5 rejected");
+        }
+        {   // K6
+            wrk::MatJob jobs[2] = {job6(L.ffn_w_k, vec(s.ffn_kx), vec(s.ffn_k, F), WRK_ACT_SQUARED_RELU), job6(L.ffn_w_r, vec(s.ffn_rx), vec(s.ffn_r), WRK_ACT_NONE)};
+            if (single) {
+                const wrk_buf* mx[2] = {L.ffn_mix_k, L.ffn_mix_r};
+                for (int i = 0; i < 2; ++i) {
+                    jobs[i].in = vec(s.x);
+                    jobs[i].pro = 1; jobs[i].pro_eps = LN_EPS; jobs[i].ln_w = L.ln2_w->ptr; jobs[i].ln_b = L.ln2_b->ptr;
+                    jobs[i].mixw = mx[i]->ptr; jobs[i].prev = rowf;
+                }
+                jobs[0].ln_out = s.ffn_x;
+            } else {
+                wrk::LnMixParams P{};
+                P.src = (const f16*)s.x; P.ln_w = (const f16*)L.ln2_w->ptr; P.ln_b = (const f16*)L.ln2_b->ptr; P.eps = LN_EPS;
+                P.d = D; P.nmix = 2; P.mix[0] = (const f16*)L.ffn_mix_k->ptr; P.mix[1] = (const f16*)L.ffn_mix_r->ptr;
+                P.out[0] = (f16*)s.ffn_kx; P.out[1] = (f16*)s.ffn_rx; P.ln_out = (f16*)s.ffn_x;
+                P.state_row = lst + (size_t)(S + 1) * D; P.state_stride = (size_t)(S + 2) * D; P.cursors = s.cursors;
+                LNMIX(P, T);
+            }
+            if (run_jobs(jobs, 2) != 0) return wrk_fail(ctx, WRK_E_ARG, "fused V6 K6 rejected");
+        }
+        {   // K7
+            wrk::MatJob j = job6(L.ffn_w_v, vec(s.ffn_k, F), vec(s.ffn_v), WRK_ACT_NONE);
+            if (single) {
+                j.out = vec(s.x); j.has_res = 1; j.res = vec(s.x); j.gate = s.ffn_r; j.carry_src = s.ffn_x; j.carry_dst = rowf;
+                if (run_jobs(&j, 1) != 0) return wrk_fail(ctx, WRK_E_ARG, "fused V6 K7 rejected");
+            } else {
+                if (run_jobs(&j, 1) != 0) return wrk_fail(ctx, WRK_E_ARG, "fused V6 K7 rejected");
+                DTensor st_ffn = make_dense(lst, WRK_F32, D, S + 2, st->num_batch);
+                st_ffn.offset[1] = S + 1; st_ffn.shape[1] = 1;
+                wrk::channel_mix_v6(q, s.cursors, st_ffn, vec(s.ffn_r), vec(s.ffn_v), vec(s.ffn_x));
+                wrk::binary(q, 0, vec(s.ffn_x), vec(s.x), 0, 0, 0);
+            }
+        }
+        if ((li + 1) % d.rescale == 0) wrk::affine(q, vec(s.x), 0.5f, 0.0f);                             // v6.rs:953-955
+    }
+    if (NH > 0) {
+        wrk::LnMixParams P{};
+        P.src = (const f16*)s.x; P.ids = identity ? nullptr : s.headers;
+        P.ln_w = (const f16*)d.ln_out_w->ptr; P.ln_b = (const f16*)d.ln_out_b->ptr; P.eps = LN_EPS;
+        P.d = D; P.nmix = 0; P.ln_out = (f16*)s.head_x;
+        LNMIX(P, NH);
+        wrk::MatJob j = job6(d.head, make_dense(s.head_x, WRK_F16, D, NH), make_dense(s.head_o, WRK_F32, V, NH), WRK_ACT_NONE);
+        if (run_jobs(&j, 1) != 0) return wrk_fail(ctx, WRK_E_ARG, "fused V6 head rejected");
+    }
+#undef LNMIX
+    WRK_LAUNCH_CHECK(ctx);
+    return WRK_OK;
+}
+
 static void for_each_handle(wrk_v6_model* m, void (*fb)(const wrk_buf*), void (*fm)(const wrk_matrix*)) {
     fb(m->d.ln0_w); fb(m->d.ln0_b); fb(m->d.ln_out_w); fb(m->d.ln_out_b); fb(m->d.emb_f16); fm(m->d.head);
     for (auto& L : m->layers) {
@@ -257,7 +563,7 @@ int32_t wrk_v6_state_create(wrk_ctx* ctx, const wrk_v6_model* model, uint32_t nu
 }
 
 int32_t wrk_v6_infer(wrk_ctx* ctx, wrk_v6_model* m, wrk_v7_state* st, const uint32_t* tokens, const uint16_t* emb_rows, const uint32_t* cursors,
-                     uint32_t T, const uint32_t* headers, uint32_t NH, float* logits, uint32_t* argmax, uint32_t) {
+                     uint32_t T, const uint32_t* headers, uint32_t NH, float* logits, uint32_t* argmax, uint32_t mode) {
     if (!ctx || !m || !st) return WRK_E_ARG;
     LOCK(ctx);
     WRK_HIP(ctx, hipSetDevice(ctx->device));
@@ -266,11 +572,13 @@ int32_t wrk_v6_infer(wrk_ctx* ctx, wrk_v6_model* m, wrk_v7_state* st, const uint
     WRK_ARG(ctx, st->num_emb == m->d.num_emb && st->num_layer == m->d.num_layer, "state does not belong to this model");
     const uint32_t D = m->d.num_emb, V = m->d.num_vocab;
     std::vector<uint8_t> seen(256, 0);
+    bool one_token_each = true;
     for (uint32_t t = 0; t < T; ++t) {
         const uint32_t c = cursors[t], b = c & 0xff, tok = (c >> 8) & 0xffff, len = c >> 24;
         WRK_ARG(ctx, b < st->num_batch, "cursor %u: batch %u >= %u", t, b, st->num_batch);
         WRK_ARG(ctx, len >= 1 && tok <= t && t < tok + len && tok + len <= T, "cursor %u: bad range", t);
         if (tok == t) { WRK_ARG(ctx, !seen[b], "cursor %u: batch %u appears twice", t, b); seen[b] = 1; }
+        if (len != 1) one_token_each = false;
         if (tokens) WRK_ARG(ctx, tokens[t] < V, "token %u: id %u >= vocab %u", t, tokens[t], V);
     }
     bool identity = (NH == T);
@@ -288,7 +596,9 @@ int32_t wrk_v6_infer(wrk_ctx* ctx, wrk_v6_model* m, wrk_v7_state* st, const uint
         rc = wrk_buf_write_raw(ctx, m->s.input, emb_rows, (size_t)T * D * 2);
         if (rc != WRK_OK) return rc;
     }
-    rc = m->enqueue_ops(st, T, NH, identity);
+    rc = WRK_E_UNSUPPORTED;
+    if (mode == 1 && one_token_each) rc = m->enqueue_fused_decode(st, T, NH, identity, cursors[0] & 0xff);
+    if (rc == WRK_E_UNSUPPORTED) rc = m->enqueue_ops(st, T, NH, identity);
     if (rc != WRK_OK) return rc;
     if (NH && argmax) wrk::argmax_rows(ctx->stream, m->s.head_o, V, V, NH, m->s.argmax);
     WRK_LAUNCH_CHECK(ctx);
@@ -299,7 +609,7 @@ int32_t wrk_v6_infer(wrk_ctx* ctx, wrk_v6_model* m, wrk_v7_state* st, const uint
 }
 
 int32_t wrk_v6_generate_greedy(wrk_ctx* ctx, wrk_v6_model* m, wrk_v7_state* st, const uint32_t* first_tokens, uint32_t B, uint32_t steps,
-                               uint32_t* out_tokens, float* last_logits, float* elapsed_ms, uint32_t) {
+                               uint32_t* out_tokens, float* last_logits, float* elapsed_ms, uint32_t mode) {
     if (!ctx || !m || !st || !first_tokens) return WRK_E_ARG;
     LOCK(ctx);
     WRK_HIP(ctx, hipSetDevice(ctx->device));
@@ -324,14 +634,16 @@ int32_t wrk_v6_generate_greedy(wrk_ctx* ctx, wrk_v6_model* m, wrk_v7_state* st, 
     const bool eager = ng && ng[0] == '1';
     auto enqueue_step = [&]() -> int32_t {
         wrk::gather_rows_f16(ctx->stream, m->d.emb_f16->ptr, m->s.tokens, m->s.input, D, B);
-        int32_t r = m->enqueue_ops(st, B, B, true);
+        int32_t r = WRK_E_UNSUPPORTED;
+        if (mode == 1) r = m->enqueue_fused_decode(st, B, B, true, 0);
+        if (r == WRK_E_UNSUPPORTED) r = m->enqueue_ops(st, B, B, true);
         if (r != WRK_OK) return r;
         wrk::argmax_rows(ctx->stream, m->s.head_o, V, V, B, m->s.argmax);
         wrk::advance_tokens(ctx->stream, m->s.argmax, m->s.tokens, m->history, m->s.counter, B);
         return WRK_OK;
     };
     wrk_program* prog = nullptr;
-    const auto key = std::make_pair((const void*)st, B);
+    const auto key = std::make_tuple((const void*)st, B, mode);
     if (!eager) {
         auto it = m->graphs.find(key);
         if (it != m->graphs.end()) prog = it->second;

@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "wrk_internal.h"
+#include "wrk_device.h"
 
 struct wrk_v7_state {
     wrk_ctx* ctx = nullptr;
@@ -66,3 +67,25 @@ void advance_tokens(hipStream_t s, const uint32_t* argmax, uint32_t* tokens, uin
 void argmax_finish(hipStream_t s, const float* pv, const uint32_t* pi, uint32_t nwg, uint32_t ntok, uint32_t* argmax, uint32_t* tokens,
                    uint32_t* history, uint32_t* counter);
 }
+
+// ------------------------------------------------------------------ shared by the fused V7 / V6 decode paths (wrk_v7_fused.hip)
+namespace wrk {
+// K0 / K4: layer norm + token shifts of stacked tokens, one workgroup per token
+struct LnMixParams {
+    const f16* src;             // [T][D] rows, or the embedding table when `ids` is set
+    const uint32_t* ids;        // optional row index per token (embedding gather / header rows)
+    const f16 *ln_w, *ln_b;
+    float eps;
+    uint32_t d, nmix;
+    const f16* mix[6];          // token-shift factors
+    f16* out[6];                // shifted outputs [T][D]
+    f16* ln_out;                // optional: LN output [T][D]
+    float* state_row;           // optional: shift state row, element (batch, c) at state_row[batch * state_stride + c]
+    size_t state_stride;
+    const uint32_t* cursors;    // batch id per token
+    uint32_t no_carry;          // 1: leave the shift state alone (a later kernel of the layer still reads it: RWKV-6)
+};
+int ln_mix(hipStream_t s, const LnMixParams& P, uint32_t T);      // -1: unsupported shape (D % 8, D > 8192, nmix not in {0, 1, 2, 6})
+void argmax_finish(hipStream_t s, const float* pv, const uint32_t* pi, uint32_t nwg, uint32_t ntok, uint32_t* argmax, uint32_t* tokens,
+                   uint32_t* history, uint32_t* counter);
+}  // namespace wrk

@@ -42,20 +42,6 @@ void advance_tokens(hipStream_t s, const uint32_t* argmax, uint32_t* tokens, uin
 // ------------------------------------------------------------------ K0 / K4: layer norm + token shifts
 // One workgroup per token.  Every global load (row, LN weights, previous shift state, mix factors)
 // is issued up front as 16-byte vectors: the kernel is one memory round trip + two block reductions.
-struct LnMixParams {
-    const f16* src;             // [T][D] rows, or the embedding table when `ids` is set
-    const uint32_t* ids;        // optional row index per token (embedding gather / header rows)
-    const f16 *ln_w, *ln_b;
-    float eps;
-    uint32_t d, nmix;
-    const f16* mix[6];          // token-shift factors
-    f16* out[6];                // shifted outputs [T][D]
-    f16* ln_out;                // optional: LN output [T][D]
-    float* state_row;           // optional: shift state row, element (batch, c) at state_row[batch * state_stride + c]
-    size_t state_stride;
-    const uint32_t* cursors;    // batch id per token
-};
-
 template <int VPT, int NMIX>
 __global__ void __launch_bounds__(256) ln_mix_kernel(const LnMixParams P) {
     __shared__ float red[4];
@@ -118,14 +104,16 @@ __global__ void __launch_bounds__(256) ln_mix_kernel(const LnMixParams P) {
                 *(f16x8*)(P.out[m] + (size_t)t * D + i * 8) = o;
             }
             // shift-state carry (time_mix_v7.wgsl:156-158 / channel_mix.wgsl:99-101)
-            f32x4 n0 = {y[0], y[1], y[2], y[3]}, n1 = {y[4], y[5], y[6], y[7]};
-            *(f32x4*)(st + i * 8) = n0;
-            *(f32x4*)(st + i * 8 + 4) = n1;
+            if (!P.no_carry) {
+                f32x4 n0 = {y[0], y[1], y[2], y[3]}, n1 = {y[4], y[5], y[6], y[7]};
+                *(f32x4*)(st + i * 8) = n0;
+                *(f32x4*)(st + i * 8 + 4) = n1;
+            }
         }
     }
 }
 
-static int ln_mix(hipStream_t s, const LnMixParams& P, uint32_t T) {
+int ln_mix(hipStream_t s, const LnMixParams& P, uint32_t T) {
     const uint32_t nvec = P.d >> 3;
     const int vpt = nvec <= 256 ? 1 : (nvec <= 512 ? 2 : (nvec <= 1024 ? 4 : 0));
     if (vpt == 0 || (P.d & 7u)) return -1;
@@ -133,6 +121,7 @@ static int ln_mix(hipStream_t s, const LnMixParams& P, uint32_t T) {
 #define LN_SWITCH(M) do { if (vpt == 1) LN_LAUNCH(1, M); else if (vpt == 2) LN_LAUNCH(2, M); else LN_LAUNCH(4, M); } while (0)
     if (P.nmix == 0) LN_SWITCH(0);
     else if (P.nmix == 1) LN_SWITCH(1);
+    else if (P.nmix == 2) LN_SWITCH(2);
     else if (P.nmix == 6) LN_SWITCH(6);
     else return -1;
 #undef LN_SWITCH
