@@ -153,6 +153,10 @@ int32_t wrk_matrix_quantize(wrk_ctx* ctx, uint32_t kind, uint32_t k, uint32_t m,
                             const wrk_buf* f16_data, const float* levels, wrk_matrix** out);
 /* read the quantised planes back in wrk_matrix_create's layout (tests; Matrix serialisation): INT8 / NF4 only */
 int32_t wrk_matrix_export(wrk_matrix* mat, void* dst, size_t capacity, size_t* bytes);
+/* Loader::load_matrix_discount (loader.rs:923-951): the reference multiplies every weight by 2^-(layer / rescale) at load,
+ * which forces the F16 path.  A power-of-two factor commutes with the contraction, so the blocks stay quantised and the
+ * factor is applied to the f32 dot product instead: y = act(scale * (W . x)). */
+int32_t wrk_matrix_set_scale(wrk_matrix* mat, float scale);
 int32_t wrk_matrix_release(wrk_matrix* mat);
 /* stored bytes read per full pass over the matrix (the roofline's algorithmic bytes) */
 size_t wrk_matrix_stream_bytes(const wrk_matrix* mat);

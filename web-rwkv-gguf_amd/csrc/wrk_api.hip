@@ -4,6 +4,7 @@
 // wrk_matvec.hip on the context's stream.
 #include "wrk_internal.h"
 
+#include <cmath>
 #include <memory>
 
 #define LOCK(ctx) std::lock_guard<std::recursive_mutex> _lk((ctx)->mu)
@@ -344,6 +345,12 @@ int32_t wrk_matrix_export(wrk_matrix* mat, void* dst, size_t capacity, size_t* b
     return WRK_OK;
 }
 
+int32_t wrk_matrix_set_scale(wrk_matrix* mat, float scale) {
+    if (!mat || !(scale > 0.0f) || !std::isfinite(scale)) return WRK_E_ARG;
+    mat->out_scale = scale;
+    return WRK_OK;
+}
+
 int32_t wrk_matrix_release(wrk_matrix* mat) {
     if (!mat) return WRK_E_ARG;
     if (mat->refs.fetch_sub(1) == 1) {
@@ -394,6 +401,7 @@ int32_t wrk_op_matmul(wrk_ctx* ctx, const wrk_matrix* mat, const wrk_tensor* inp
     WRK_ARG(ctx, input->view.shape[1] == output->view.shape[1] && input->view.shape[2] == output->view.shape[2], "matmul: token/batch mismatch");
     wrk::MatJob j{mat->data, mat->aux, mat->kind, mat->flags, mat->k, mat->m, (uint32_t)mat->row_bytes,
                   make_dtensor(input), make_dtensor(output), act, (uint32_t)sparse};
+    j.scale = mat->out_scale;
     int rc = -2;
     const size_t ntok = (size_t)input->view.shape[1] * input->view.shape[2];
     if (turbo && ntok >= 16) rc = wrk::matmul_mfma(ctx->stream, j, ctx->num_cu);

@@ -67,6 +67,7 @@ struct GemmParams {
     uint32_t n;                 // tokens
     uint32_t has_res;
     uint32_t wg_begin;          // first workgroup (in x) of this job
+    float scale;                // wrk_matrix::out_scale
     DTensor in, out, res;       // [K, T, B], [M, T, B]
 };
 
@@ -314,7 +315,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& P, float (*sh_tot)[N
         for (int i = 0; i < 4; ++i) {
             const uint32_t mr = m0 + 4 * g + i;
             if (mr >= P.m) continue;
-            float o = act_apply(P.act, total[t][i]);
+            float o = act_apply(P.act, total[t][i] * P.scale);
             if (P.has_res) { uint32_t rt, rb; tok_tb(P.res, tok, rt, rb); o = dt_round(P.out, o) + dt_load(P.res, dt_index(P.res, mr, rt, rb)); }
             dt_store(P.out, dt_index(P.out, mr, tt, bb), o);
         }
@@ -461,7 +462,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmParams& P, f16* __restr
         for (int i = 0; i < 4; ++i) {
             const uint32_t mr = m0 + 4 * g + i;
             if (mr >= P.m) continue;
-            float o = act_apply(P.act, total[t][i]);
+            float o = act_apply(P.act, total[t][i] * P.scale);
             if (P.has_res) { uint32_t rt, rb; tok_tb(P.res, tok, rt, rb); o = dt_round(P.out, o) + dt_load(P.res, dt_index(P.res, mr, rt, rb)); }
             dt_store(P.out, dt_index(P.out, mr, tt, bb), o);
         }
@@ -529,7 +530,7 @@ __device__ __forceinline__ void gemm_tile_body_f16(const GemmParams& P, f16* __r
         for (int i = 0; i < 4; ++i) {
             const uint32_t mr = m0 + 4 * g + i;
             if (mr >= P.m) continue;
-            float o = act_apply(P.act, total[t][i]);
+            float o = act_apply(P.act, total[t][i] * P.scale);
             if (P.has_res) { uint32_t rt, rb; tok_tb(P.res, tok, rt, rb); o = dt_round(P.out, o) + dt_load(P.res, dt_index(P.res, mr, rt, rb)); }
             dt_store(P.out, dt_index(P.out, mr, tt, bb), o);
         }
@@ -570,7 +571,7 @@ static bool gemm_ok(const MatJob& j, uint32_t n) {
 // path (n < 16, ROUND_F16, non-f16 / unaligned input, K % 32, Int8 / NF4): the caller falls back to the matvec kernels.
 static void fill_job(GemmParams& P, const MatJob& j, uint32_t n, uint32_t wg_begin) {
     P.w = j.w; P.kind = j.kind; P.k = j.k; P.m = j.m; P.row_bytes = j.row_bytes; P.act = j.act; P.n = n;
-    P.has_res = j.has_res; P.in = j.in; P.out = j.out; P.res = j.res; P.wg_begin = wg_begin;
+    P.has_res = j.has_res; P.in = j.in; P.out = j.out; P.res = j.res; P.wg_begin = wg_begin; P.scale = j.scale;
 }
 
 int matmul_mfma_multi(hipStream_t s, const MatJob* jobs, int njobs, int) {

@@ -44,6 +44,7 @@ struct wrk_matrix {
     uint8_t* aux = nullptr;     // Matrix::Fp4 { q }: the 16 f32 levels (device); side tables live in the row planes
     size_t aux_bytes = 0;
     std::atomic<int> refs;
+    float out_scale = 1.0f;     // y = out_scale * (W . x): the 2^-k layer discount of load_matrix_discount kept OUT of the blocks
 };
 
 struct wrk_program {
@@ -173,6 +174,7 @@ struct MatJob {
     void* ln_out = nullptr;         // f16 [K]: LN(in), published by the first workgroup of the job
     const void* carry_src = nullptr;    // epilogue: carry_dst[row] = carry_src[row]
     float* carry_dst = nullptr;
+    float scale = 1.0f;                 // wrk_matrix::out_scale
     const void* gate = nullptr;         // f16 [M]: out = round(sigmoid(gate[row]) * round(act(W.x)))  (channel_mix.wgsl:104-106, RWKV-6), before the residual
     unsigned long long* dbg = nullptr;  // WRK_TIMING=1: 16 device timestamps of this launch (first and last workgroup)
 };

@@ -242,6 +242,7 @@ struct JobDev {
     const f16* carry_src;
     float* carry_dst;
     const f16* gate;
+    float scale;
     unsigned long long* dbg;
 };
 
@@ -614,7 +615,7 @@ __device__ __forceinline__ void matvec_body(const JobDev& J, unsigned char* smem
                 const uint32_t tk = tok0 + n;
                 if (lane == 0 && tk < ntok) {
                     const uint32_t t = tk % J.in.shape[1], b = tk / J.in.shape[1];
-                    float o = act_apply(J.act, v);
+                    float o = act_apply(J.act, v * J.scale);
                     if (J.has_res) o = dt_round(J.out, o) + dt_load(J.res, dt_index(J.res, r, t, b));
                     dt_store(J.out, dt_index(J.out, r, t, b), o);
                     if (o > best_v[n]) { best_v[n] = o; best_i[n] = r; }
@@ -765,7 +766,7 @@ __device__ __forceinline__ void matvec_body_reg(const JobDev& J, unsigned char* 
     float best_v = -3.0e38f;
     uint32_t best_i = 0xffffffffu;
     auto finish = [&](uint32_t r, float v, float resv, float carryv, float gatev) {    // activation, fused residual, store, running arg-max
-        float o = act_apply(J.act, v);
+        float o = act_apply(J.act, v * J.scale);
         if (J.gate) o = act_sigmoid(gatev) * dt_round(J.out, o);
         if (J.has_res) o = dt_round(J.out, o) + resv;
         dt_store(J.out, dt_index(J.out, r, 0, 0), o);
@@ -1027,7 +1028,7 @@ int matvec(hipStream_t s, const MatJob* jobs, int njobs, int num_cu, bool dry_ru
         d.amax_val = jobs[j].amax_val; d.amax_idx = jobs[j].amax_idx;
         d.pro = jobs[j].pro; d.pro_eps = jobs[j].pro_eps; d.ln_w = (const f16*)jobs[j].ln_w; d.ln_b = (const f16*)jobs[j].ln_b;
         d.mixw = (const f16*)jobs[j].mixw; d.prev = jobs[j].prev; d.ln_out = (f16*)jobs[j].ln_out;
-        d.carry_src = (const f16*)jobs[j].carry_src; d.carry_dst = jobs[j].carry_dst; d.gate = (const f16*)jobs[j].gate; d.dbg = jobs[j].dbg;
+        d.carry_src = (const f16*)jobs[j].carry_src; d.carry_dst = jobs[j].carry_dst; d.gate = (const f16*)jobs[j].gate; d.scale = jobs[j].scale; d.dbg = jobs[j].dbg;
         wg += (jobs[j].m + d.rows_per_wg - 1) / d.rows_per_wg;
     }
     const uint32_t kpad = (kmax + 15u) & ~15u;

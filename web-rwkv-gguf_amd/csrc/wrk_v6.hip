@@ -88,6 +88,7 @@ int32_t wrk_v6_model::ensure_history(size_t n) {
 
 static int32_t mm6(wrk_ctx* ctx, const wrk_matrix* m, DTensor in, DTensor out, uint32_t act) {
     wrk::MatJob j{m->data, m->aux, m->kind, m->flags, m->k, m->m, (uint32_t)m->row_bytes, in, out, act, 0};
+    j.scale = m->out_scale;
     int rc = -2;
     if (in.shape[1] * in.shape[2] >= wrk::gemm_min_tokens()) rc = wrk::matmul_mfma(ctx->stream, j, ctx->num_cu);
     if (rc == -2) rc = wrk::matvec(ctx->stream, &j, 1, ctx->num_cu);
@@ -326,7 +327,9 @@ __global__ void __launch_bounds__(256) v6_head_kernel(const V6HeadParams P) {
 }  // namespace wrk
 
 static wrk::MatJob job6(const wrk_matrix* m, DTensor in, DTensor out, uint32_t act) {
-    return wrk::MatJob{m->data, m->aux, m->kind, m->flags, m->k, m->m, (uint32_t)m->row_bytes, in, out, act, 0};
+    wrk::MatJob j{m->data, m->aux, m->kind, m->flags, m->k, m->m, (uint32_t)m->row_bytes, in, out, act, 0};
+    j.scale = m->out_scale;
+    return j;
 }
 
 // One decode step for T stacked tokens, each its own sequence.  Returns WRK_E_UNSUPPORTED (without launching anything)

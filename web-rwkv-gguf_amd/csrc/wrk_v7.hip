@@ -86,7 +86,9 @@ int32_t wrk_v7_model::ensure_scratch(uint32_t T, uint32_t NH) {
 }
 
 static wrk::MatJob mj(const wrk_matrix* m, DTensor in, DTensor out, uint32_t act) {
-    return wrk::MatJob{m->data, m->aux, m->kind, m->flags, m->k, m->m, (uint32_t)m->row_bytes, in, out, act, 0};
+    wrk::MatJob j{m->data, m->aux, m->kind, m->flags, m->k, m->m, (uint32_t)m->row_bytes, in, out, act, 0};
+    j.scale = m->out_scale;
+    return j;
 }
 
 static int32_t mm(wrk_ctx* ctx, const wrk_matrix* m, DTensor in, DTensor out, uint32_t act) {

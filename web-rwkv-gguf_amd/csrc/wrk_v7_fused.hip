@@ -394,7 +394,9 @@ void wrk_v7_model::free_fused() {
 }
 
 static wrk::MatJob job(const wrk_matrix* m, DTensor in, DTensor out, uint32_t act) {
-    return wrk::MatJob{m->data, m->aux, m->kind, m->flags, m->k, m->m, (uint32_t)m->row_bytes, in, out, act, 0};
+    wrk::MatJob j{m->data, m->aux, m->kind, m->flags, m->k, m->m, (uint32_t)m->row_bytes, in, out, act, 0};
+    j.scale = m->out_scale;
+    return j;
 }
 
 int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_t NH, bool identity_headers, bool from_tokens,

@@ -930,12 +930,15 @@ int32_t wrk_runtime_create(wrk_ctx* ctx, const wrk_gguf* g, const wrk_build_opti
             *o = mt;
             return WRK_OK;
         }
-        const bool direct = big && weights != WRK_WEIGHTS_REFERENCE && discount == 1.0f &&
+        // the layer discount 2^-(layer / rescale) is a power of two: it is applied to the dot product (wrk_matrix_set_scale)
+        // and the blocks stay quantised, instead of forcing the F16 path as load_matrix_discount does
+        const bool direct = big && weights != WRK_WEIGHTS_REFERENCE &&
                             (ti->type == T_Q4K || ti->type == T_Q5K || ti->type == T_Q6K || ti->type == T_Q8_0) &&
                             (ti->type == T_Q8_0 ? k % 32 == 0 : k % 256 == 0);
         if (direct) {
             r = wrk_matrix_create(ctx, ti->type, k, m, g->tensor_data(*ti), ti->data_size(),
                                   weights == WRK_WEIGHTS_INLINE_F16 ? WRK_MATRIX_ROUND_F16 : WRK_MATRIX_EXACT, &mt);
+            if (r == WRK_OK && discount != 1.0f) r = wrk_matrix_set_scale(mt, discount);
         } else {
             std::vector<uint16_t> v;
             r = g->tensor_f16(name, v);

@@ -94,6 +94,7 @@ HIP_SYMBOLS = {
     "wrk_matrix_create": (C.c_int32, [_P, C.c_uint32, C.c_uint32, C.c_uint32, _P, C.c_size_t, C.c_uint32, C.POINTER(_P)]),
     "wrk_matrix_quantize": (C.c_int32, [_P, C.c_uint32, C.c_uint32, C.c_uint32, _P, C.POINTER(C.c_float), C.POINTER(_P)]),
     "wrk_matrix_export": (C.c_int32, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "wrk_matrix_set_scale": (C.c_int32, [_P, C.c_float]),
     "wrk_matrix_release": (C.c_int32, [_P]),
     "wrk_matrix_stream_bytes": (C.c_size_t, [_P]),
     "wrk_op_matmul": (C.c_int32, [_P, _P, _TP, _TP, C.c_uint32, C.c_int32, C.c_int32]),
@@ -332,6 +333,10 @@ class Matrix:
         out = np.empty(n.value, np.uint8)
         self.ctx.check(hip.wrk_matrix_export(self.h, out.ctypes.data_as(_P), out.nbytes, C.byref(n)))
         return out
+
+    def set_scale(self, scale: float):
+        """y = act(scale * (W . x)): `load_matrix_discount`'s 2^-k factor without leaving the quantised form."""
+        self.ctx.check(hip.wrk_matrix_set_scale(self.h, scale))
 
     @property
     def stream_bytes(self) -> int:
