@@ -33,7 +33,9 @@ def make(kind, k, m, seed):
 CASES = [("Q4_K", 256, 7), ("Q4_K", 2048, 64), ("Q4_K", 2560, 33), ("Q4_K", 8192, 16),
          ("Q5_K", 512, 9), ("Q5_K", 4096, 32), ("Q6_K", 256, 5), ("Q6_K", 2048, 130), ("Q6_K", 2560, 12),
          ("Q8_0", 96, 10), ("Q8_0", 4096, 40), ("Q8_0", 64, 2048),
-         ("F16", 96, 2048), ("F16", 2048, 96), ("F16", 768, 100), ("F32", 256, 64)]
+         ("F16", 96, 2048), ("F16", 2048, 96), ("F16", 768, 100), ("F32", 256, 64),
+         # rows longer than 8192 (block kinds) / 2048 (F16): K split over the waves with two chunk iterations (RWKV-6 7B shapes)
+         ("Q5_K", 14336, 20), ("Q4_K", 16384, 8), ("Q6_K", 10240, 12), ("Q8_0", 12288, 9), ("F16", 4096, 40)]
 
 
 @pytest.mark.parametrize("kind,k,m", CASES)

@@ -656,7 +656,8 @@ __device__ __forceinline__ void matvec_body_reg(const JobDev& J, unsigned char* 
     // rows in flight per wave: everything a wave owns (<= 4 rows for <= 16 rows per workgroup) goes out in ONE round
     // trip -- the in-kernel timeline (WRK_TIMING) showed a second trip costs 1.2 us, a third of the kernel
     constexpr int RB = 4;
-    static_assert(KS == 1 || XI == 1, "K-split uses one chunk iteration per wave");
+    static_assert(KS == 1 || XI <= 2, "K-split: one or two chunk iterations per wave (K <= 16384 for the block kinds)");
+    constexpr uint32_t CSTEP = KS == 1 ? 64u : 256u;       // chunk stride between a lane's iterations
     const uint32_t K = J.k;
     const uint32_t kpad = (K + 15u) & ~15u;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -673,7 +674,7 @@ __device__ __forceinline__ void matvec_body_reg(const JobDev& J, unsigned char* 
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
             for (int ci = 0; ci < XI; ++ci) {
-                const uint32_t c = cbase + 64 * ci;
+                const uint32_t c = cbase + CSTEP * ci;
                 if (ri0 + rb < nrows && c < nch) raw[rb][ci] = load_raw<KIND>(J.w + (size_t)row_of(ri0 + rb) * J.row_bytes, K, c);
             }
     };
@@ -752,10 +753,10 @@ __device__ __forceinline__ void matvec_body_reg(const JobDev& J, unsigned char* 
         for (uint32_t i = K + tid; i < kpad; i += 256) xs[i] = (f16)0.0f;
         __syncthreads();
 #pragma unroll
-        for (int ci = 0; ci < XI; ++ci) x[ci] = load_x<KIND>(xs, cbase + 64 * ci, cbase + 64 * ci < nch);
+        for (int ci = 0; ci < XI; ++ci) x[ci] = load_x<KIND>(xs, cbase + CSTEP * ci, cbase + CSTEP * ci < nch);
     } else {
 #pragma unroll
-        for (int ci = 0; ci < XI; ++ci) x[ci] = load_x<KIND>(xin, cbase + 64 * ci, cbase + 64 * ci < nch);
+        for (int ci = 0; ci < XI; ++ci) x[ci] = load_x<KIND>(xin, cbase + CSTEP * ci, cbase + CSTEP * ci < nch);
         issue(0);
     }
 #pragma unroll
@@ -781,7 +782,7 @@ __device__ __forceinline__ void matvec_body_reg(const JobDev& J, unsigned char* 
             acc[rb] = 0.0f;
 #pragma unroll
             for (int ci = 0; ci < XI; ++ci) {
-                const uint32_t c = cbase + 64 * ci;
+                const uint32_t c = cbase + CSTEP * ci;
                 if (ri0 + rb < nrows && c < nch) acc[rb] += dot_raw_reg<KIND, R16>(raw[rb][ci], c, x[ci]);
             }
         }
@@ -930,18 +931,21 @@ static matvec_fn pick_reg(const MatvecParams& P, int quant, bool has_f16, bool r
         else { nch = J.kind == WRK_MAT_Q8_0 ? (J.k >> 4) : (J.k >> 8) * 8; need = (nch + 63) / 64; }
         xi = need > xi ? need : xi;
     }
-    if (xi > 4) return nullptr;
+    if (xi > 8) return nullptr;
+    bool small_wg = true;       // the K-split kernels combine <= 32 rows per workgroup in LDS
+    for (int j = 0; j < P.njobs; ++j) if (P.jobs[j].rows_per_wg > 32) small_wg = false;
     if (quant < 0) {    // F16-only launch
         if (xi == 1) return (matvec_fn)matvec_reg_kernel<WRK_MAT_F16, WRK_MAT_F16, false, 1, 1>;
         if (xi == 2) return (matvec_fn)matvec_reg_kernel<WRK_MAT_F16, WRK_MAT_F16, false, 2, 1>;
-        return (matvec_fn)matvec_reg_kernel<WRK_MAT_F16, WRK_MAT_F16, false, 4, 1>;
+        if (xi <= 4) return (matvec_fn)matvec_reg_kernel<WRK_MAT_F16, WRK_MAT_F16, false, 4, 1>;
+        return small_wg ? (matvec_fn)matvec_reg_kernel<WRK_MAT_F16, WRK_MAT_F16, false, 2, 4> : nullptr;     // 2048 < K <= 4096 (F16)
     }
     const int kb = has_f16 ? WRK_MAT_F16 : quant;
     if (xi == 1) return pick_reg_kernel<1, 1>(quant, kb, r16);
     if (xi == 2) return pick_reg_kernel<2, 1>(quant, kb, r16);
-    if (has_f16) return nullptr;                    // K-split kernels are single-kind
-    for (int j = 0; j < P.njobs; ++j) if (P.jobs[j].rows_per_wg > 32) return nullptr;
-    return pick_reg_kernel<1, 4>(quant, quant, r16); // 2048 < K <= 8192 for the block kinds: split K over the 4 waves
+    if (has_f16 || !small_wg) return nullptr;       // K-split kernels are single-kind
+    if (xi <= 4) return pick_reg_kernel<1, 4>(quant, quant, r16);     // 4096 < K <= 8192 for the block kinds: K over the 4 waves
+    return pick_reg_kernel<2, 4>(quant, quant, r16);                  // 8192 < K <= 16384
 }
 
 template <int NB>
