@@ -549,6 +549,127 @@ __global__ void __launch_bounds__(256) gemm_tile_kernel(const GemmBatch B) {
     else gemm_tile_body_f16(P, (f16*)tile_smem);
 }
 
+// ------------------------------------------------------------------ decode-batch tile kernel (Q4_K / Q5_K, <= 16 tokens)
+// Same idea as the prefill tile for the few-token regime of batched decode: 64 rows x 16 tokens per workgroup, every
+// wave walks the whole K for its 16 rows, the 16 x 256 activation block is shared through LDS (8 KB per block, double
+// buffered).  Against the K-split kernel this (a) reads the activations once per 64 rows instead of once per 16 (at
+// D = 4096 the K-split kernel moves 128 KB of activations per 45 KB of weights), and (b) takes the B fragments off the
+// vector-memory queue (LDS has its own counter), so the weight rows can be prefetched FOUR blocks ahead without the
+// in-order return of loads stalling the multiply.
+template <int KIND>
+__device__ __forceinline__ void gemm_dec_body(const GemmParams& P, f16* __restrict__ lds) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t r = lane & 15, g = lane >> 4;
+    const uint32_t m0 = (blockIdx.x - P.wg_begin) * TILE_ROWS + wave * 16;
+    const uint32_t K = P.k, nb = K >> 8;
+    const uint32_t row = min(m0 + r, P.m - 1);
+    const uint8_t* wrow = P.w + (size_t)row * P.row_bytes;
+    const uint32_t hoff = KIND == WRK_MAT_Q4_K ? nb * 128 : nb * 160, soff = hoff + nb * 4;
+    const uint8_t* crow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) crow[i] = P.w + (size_t)min(m0 + 4 * g + i, P.m - 1) * P.row_bytes + hoff;
+    // staging: 16 tokens x 32 chunks of 8 f16 per block, 2 per thread: chunk q -> token (tid >> 5) + 8 q
+    const size_t xs0 = P.in.stride[0];
+    const f16* xbase = (const f16*)P.in.p + dt_index(P.in, 0, 0, 0) + (size_t)(tid >> 5) * xs0 + (tid & 31u) * 8;
+    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    f16x8 stage[2];
+    auto fetch_x = [&](uint32_t b) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) stage[q] = ((tid >> 5) + 8 * q < P.n) ? *(const f16x8*)(xbase + (size_t)8 * q * xs0 + (size_t)b * 256) : zero8;
+    };
+    auto store_x = [&](uint32_t buf) {
+        f16* base = lds + (size_t)buf * 16 * TILE_LDS_ROW;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) *(f16x8*)(base + ((tid >> 5) + 8 * q) * TILE_LDS_ROW + (tid & 31u) * 8) = stage[q];
+    };
+    struct WBlk { u32x2 q[4]; u32x2 qh; u32x4 sm; uint32_t dd[4]; };
+    auto load_w = [&](WBlk& R, uint32_t b) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) R.q[j] = *(const u32x2*)(wrow + (size_t)b * 128 + j * 32 + 8 * g);
+        if (KIND == WRK_MAT_Q5_K) R.qh = *(const u32x2*)(wrow + (size_t)nb * 128 + (size_t)b * 32 + 8 * g);
+        R.sm = *(const u32x4*)(wrow + soff + (size_t)b * 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) R.dd[i] = *(const uint32_t*)(crow[i] + (size_t)b * 4);
+    };
+    f32x4v total = {0.f, 0.f, 0.f, 0.f};
+    auto mul_blk = [&](const WBlk& R, uint32_t buf) {
+        const f16* xt = lds + (size_t)buf * 16 * TILE_LDS_ROW + r * TILE_LDS_ROW + 8 * g;
+        f32x4v acc = {0.f, 0.f, 0.f, 0.f}, amin = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const u32x2 q = R.q[j];
+            const uint32_t v = R.sm[j];
+            const float sc0 = (float)(v & 0xffu), sc1 = (float)((v >> 8) & 0xffu);
+            f16x8 alo, ahi;
+            if (KIND == WRK_MAT_Q4_K) {
+                alo = mul8(codes8(q.x & 0x0f0f0f0fu, q.y & 0x0f0f0f0fu), sc0 * 1024.0f);
+                ahi = mul8(codes8(q.x & 0xf0f0f0f0u, q.y & 0xf0f0f0f0u), sc1 * 64.0f);
+            } else {
+                const uint32_t s0 = 2 * j, s1 = 2 * j + 1;
+                alo = mul8(codes8((q.x & 0x0f0f0f0fu) | (((R.qh.x >> s0) & 0x01010101u) << 4), (q.y & 0x0f0f0f0fu) | (((R.qh.y >> s0) & 0x01010101u) << 4)), sc0 * 1024.0f);
+                ahi = mul8(codes8(((q.x >> 4) & 0x0f0f0f0fu) | (((R.qh.x >> s1) & 0x01010101u) << 4), ((q.y >> 4) & 0x0f0f0f0fu) | (((R.qh.y >> s1) & 0x01010101u) << 4)), sc1 * 1024.0f);
+            }
+            const f16 m0h = (f16)(float)((v >> 16) & 0xffu), m1h = (f16)(float)(v >> 24);
+            const f16x8 mlo = {m0h, m0h, m0h, m0h, m0h, m0h, m0h, m0h}, mhi = {m1h, m1h, m1h, m1h, m1h, m1h, m1h, m1h};
+            const f16x8 b0 = *(const f16x8*)(xt + j * 64), b1 = *(const f16x8*)(xt + j * 64 + 32);
+            acc = mfma16(alo, b0, acc);
+            acc = mfma16(ahi, b1, acc);
+            amin = mfma16(mlo, b0, amin);
+            amin = mfma16(mhi, b1, amin);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float d = (float)__builtin_bit_cast(f16, (uint16_t)(R.dd[i] & 0xffffu)) * 16384.0f;
+            const float dmin = (float)__builtin_bit_cast(f16, (uint16_t)(R.dd[i] >> 16));
+            total[i] += d * acc[i] - dmin * amin[i];
+        }
+    };
+    WBlk W[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if ((uint32_t)u < nb) load_w(W[u], u);
+    fetch_x(0);
+    store_x(0);
+    __syncthreads();
+    for (uint32_t b0 = 0; b0 < nb; b0 += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {           // unrolled by the ring depth: every buffer index is a compile-time constant
+            const uint32_t b = b0 + u;
+            if (b >= nb) break;
+            const bool more = b + 1 < nb;
+            if (more) fetch_x(b + 1);           // L2-resident, issued BEFORE the far weight prefetch below (loads return in order)
+            mul_blk(W[u], u & 1);
+            if (b + 4 < nb) load_w(W[u], b + 4);
+            if (more) store_x((u & 1) ^ 1);
+            __syncthreads();
+        }
+    }
+    const uint32_t tok = r;
+    if (tok < P.n) {
+        uint32_t tt, bb;
+        tok_tb(P.out, tok, tt, bb);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t mr = m0 + 4 * g + i;
+            if (mr >= P.m) continue;
+            float o = act_apply(P.act, total[i] * P.scale);
+            if (P.has_res) { uint32_t rt, rb; tok_tb(P.res, tok, rt, rb); o = dt_round(P.out, o) + dt_load(P.res, dt_index(P.res, mr, rt, rb)); }
+            dt_store(P.out, dt_index(P.out, mr, tt, bb), o);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) gemm_dec_kernel(const GemmBatch B) {
+    __shared__ __attribute__((aligned(16))) f16 dec_smem[2 * 16 * TILE_LDS_ROW];
+    int ji = 0;
+#pragma unroll
+    for (int q = 1; q < GEMM_MAX_JOBS; ++q)
+        if (q < B.njobs && blockIdx.x >= B.jobs[q].wg_begin) ji = q;
+    const GemmParams& P = B.jobs[ji];
+    if (P.kind == WRK_MAT_Q4_K) gemm_dec_body<WRK_MAT_Q4_K>(P, dec_smem);
+    else gemm_dec_body<WRK_MAT_Q5_K>(P, dec_smem);
+}
+
 // fewest stacked tokens sent to the matrix cores (tiles are padded to 16 tokens; below this the matvec kernels run)
 uint32_t gemm_min_tokens() {
     static const uint32_t v = [] { const char* e = getenv("WRK_GEMM_MIN"); const int x = e ? atoi(e) : 4; return (uint32_t)(x < 2 ? 2 : x); }();     // measured: B=4 break-even, B=8 2x in favour of MFMA
@@ -582,11 +703,20 @@ int matmul_mfma_multi(hipStream_t s, const MatJob* jobs, int njobs, int) {
     // prefill regime: Q4_K / Q5_K matrices with >= 64 rows go to the LDS-tiled kernel, the rest (LoRA, Q6_K, Q8_0, F16)
     // to the K-split kernel, each group in one launch
     static const bool use_tile = [] { const char* e = getenv("WRK_GEMM_TILE"); return !(e && e[0] == '0'); }();
-    GemmBatch T, B;
-    T.njobs = B.njobs = 0;
-    uint32_t twg = 0, wg = 0, kmax = 0;
+    // measured (round 1): SLOWER than the K-split kernel -- 12.2 vs 8.9 us for 8192 x 2048 x 16 tokens, batch-16 decode 2.35 vs
+    // 1.76 ms -- 128 workgroups leave half the CUs idle and every 256-block costs a workgroup barrier.  Off unless WRK_GEMM_DEC=1.
+    static const bool use_dec = [] { const char* e = getenv("WRK_GEMM_DEC"); return e && e[0] == '1'; }();
+    GemmBatch T, B, Dq;
+    T.njobs = B.njobs = Dq.njobs = 0;
+    uint32_t twg = 0, wg = 0, kmax = 0, dwg = 0;
     for (int q = 0; q < njobs; ++q) {
         const MatJob& j = jobs[q];
+        // decode batches (<= 16 tokens): rows up to 24 blocks long go to the 64-row LDS tile; longer rows keep the K split
+        if (use_dec && n <= 16 && (j.kind == WRK_MAT_Q4_K || j.kind == WRK_MAT_Q5_K) && j.m >= 64 && j.in.shape[2] == 1 && (j.k >> 8) <= 24) {
+            fill_job(Dq.jobs[Dq.njobs++], j, n, dwg);
+            dwg += (j.m + TILE_ROWS - 1) / TILE_ROWS;
+            continue;
+        }
         // the tile kernel walks the whole K in every wave: it needs enough workgroups to fill the chip (a 2048 x 8192
         // matrix x 128 tokens has only 64 tiles and is faster on the K-split kernel: 44 vs 74 us)
         const uint32_t tiles = ((j.m + TILE_ROWS - 1) / TILE_ROWS) * ((n + TILE_TOK - 1) / TILE_TOK);
@@ -604,6 +734,7 @@ int matmul_mfma_multi(hipStream_t s, const MatJob* jobs, int njobs, int) {
         }
         gemm_tile_kernel<<<dim3(twg, (n + TILE_TOK - 1) / TILE_TOK), 256, smem, s>>>(T);
     }
+    if (Dq.njobs) gemm_dec_kernel<<<dim3(dwg), 256, 0, s>>>(Dq);
     if (B.njobs) {
         // tokens per wave: enough tiles to amortise the decode, few enough to keep >= ~2 waves per SIMD;
         // few row tiles x long rows (decode batches through ffn.value): 8 waves split K so a wave's serial chain is short
