@@ -467,14 +467,14 @@ __device__ __forceinline__ XRegs load_x(const f16* __restrict__ x, uint32_t c, b
     chunk_xoff<KIND>(c, lo, hi);
     r.v[0] = *(const f16x8*)(x + lo);
     if (KIND != WRK_MAT_F16) r.v[1] = *(const f16x8*)(x + lo + 8);
-    if (KIND != WRK_MAT_F16 && KIND != WRK_MAT_Q8_0) { r.v[2] = *(const f16x8*)(x + hi); r.v[3] = *(const f16x8*)(x + hi + 8); }
+    if (KIND != WRK_MAT_F16 && KIND != WRK_MAT_Q8_0 && KIND != WRK_MAT_INT8) { r.v[2] = *(const f16x8*)(x + hi); r.v[3] = *(const f16x8*)(x + hi + 8); }
     return r;
 }
 
 template <int KIND>
 __device__ __forceinline__ void x_sums(XRegs& r) {
     if (KIND != WRK_MAT_F16) r.s[0] = sum8(r.v[0]) + sum8(r.v[1]);
-    if (KIND != WRK_MAT_F16 && KIND != WRK_MAT_Q8_0) r.s[1] = sum8(r.v[2]) + sum8(r.v[3]);
+    if (KIND != WRK_MAT_F16 && KIND != WRK_MAT_Q8_0 && KIND != WRK_MAT_INT8) r.s[1] = sum8(r.v[2]) + sum8(r.v[3]);
 }
 
 __device__ __forceinline__ float dot16r(const f16x2 (&q)[8], const f16x8 xa, const f16x8 xb) {
@@ -513,7 +513,7 @@ __device__ __forceinline__ float dot_raw_reg(const Raw& r, uint32_t c, const XRe
     Group lo, hi;
     decode_raw<KIND>(r, c, lo, hi);
     float a = group_dot_r<R16>(lo, x.v[0], x.v[1], x.s[0]);
-    if (KIND != WRK_MAT_Q8_0) a += group_dot_r<R16>(hi, x.v[2], x.v[3], x.s[1]);
+    if (KIND != WRK_MAT_Q8_0 && KIND != WRK_MAT_INT8) a += group_dot_r<R16>(hi, x.v[2], x.v[3], x.s[1]);
     return a;
 }
 
@@ -675,7 +675,12 @@ __device__ __forceinline__ void matvec_body_reg(const JobDev& J, unsigned char* 
 #pragma unroll
             for (int ci = 0; ci < XI; ++ci) {
                 const uint32_t c = cbase + CSTEP * ci;
-                if (ri0 + rb < nrows && c < nch) raw[rb][ci] = load_raw<KIND>(J.w + (size_t)row_of(ri0 + rb) * J.row_bytes, K, c);
+                if (ri0 + rb < nrows && c < nch) {
+                    const uint32_t rr = row_of(ri0 + rb);
+                    // Int8 blocks run over the flattened matrix: the row starts `phase` 16-element chunks into a block
+                    const uint32_t phase = KIND == WRK_MAT_INT8 ? (uint32_t)((((size_t)rr * K) >> 4) & 7u) : 0u;
+                    raw[rb][ci] = load_raw<KIND>(J.w + (size_t)rr * J.row_bytes, K, c, phase);
+                }
             }
     };
     WRK_STAMP(J.dbg, 0);
@@ -911,6 +916,7 @@ static matvec_fn pick_reg_kernel(int ka, int kb, bool r16) {
     PAIR(WRK_MAT_Q5_K)
     PAIR(WRK_MAT_Q6_K)
     PAIR(WRK_MAT_Q8_0)
+    PAIR(WRK_MAT_INT8)
 #undef PAIR
     return nullptr;
 }
@@ -928,7 +934,8 @@ static matvec_fn pick_reg(const MatvecParams& P, int quant, bool has_f16, bool r
         // chunk iterations per row, in units of the QUANTISED kind's count (F16 rows carry 4x the chunks per element)
         uint32_t nch, need;
         if (J.kind == WRK_MAT_F16) { nch = kpad >> 3; need = quant < 0 ? (nch + 63) / 64 : (nch + 255) / 256; }
-        else { nch = J.kind == WRK_MAT_Q8_0 ? (J.k >> 4) : (J.k >> 8) * 8; need = (nch + 63) / 64; }
+        else if (J.kind == WRK_MAT_NF4) return nullptr;      // level-table decode lives in the LDS-staged kernel only
+        else { nch = (J.kind == WRK_MAT_Q8_0 || J.kind == WRK_MAT_INT8) ? (J.k >> 4) : (J.k >> 8) * 8; need = (nch + 63) / 64; }
         xi = need > xi ? need : xi;
     }
     if (xi > 8) return nullptr;
