@@ -68,6 +68,7 @@ struct GemmParams {
     uint32_t has_res;
     uint32_t wg_begin;          // first workgroup (in x) of this job
     float scale;                // wrk_matrix::out_scale
+    unsigned long long* dbg;    // WRK_TIMING build: stamps of this launch
     DTensor in, out, res;       // [K, T, B], [M, T, B]
 };
 
@@ -88,6 +89,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& P, float (*sh_tot)[N
     // 8 when a launch has few row tiles and long rows (ffn.value at 16 tokens: 128 workgroups x 32 blocks), so that a
     // wave's serial chain stays ~4 blocks
     const uint32_t m0 = (blockIdx.x - P.wg_begin) * 16;
+    WRK_STAMP(P.dbg, 0);
     const uint32_t row = min(m0 + r, P.m - 1);
     const uint8_t* wrow = P.w + (size_t)row * P.row_bytes;
     const uint32_t n0 = blockIdx.y * 16 * NT;
@@ -111,14 +113,47 @@ __device__ __forceinline__ void gemm_body(const GemmParams& P, float (*sh_tot)[N
 #pragma unroll
     for (int t = 0; t < NT; ++t) total[t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
 
-    if (KIND == WRK_MAT_F16) {
-        const f16* wr = (const f16*)wrow;
-        for (uint32_t k0 = 32 * wave; k0 < K; k0 += 32 * NW) {
-            const f16x8 a = (k0 + 8 * g + 8 <= K) ? *(const f16x8*)(wr + k0 + 8 * g) : zero8;
+    // residual operands of the C elements this lane stores (wave 0 does the epilogue): requested now, with the first
+    // weights, instead of as a dependent load after the last MFMA (1.4 us in the WRK_TIMING trace)
+    float resv[NT][4];
+    if (P.has_res && wave == 0) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const f16x8 bfr = (k0 + 8 * g + 8 <= K) ? loadB(t, k0) : zero8;
-                total[t] = mfma16(a, bfr, total[t]);
+        for (int t = 0; t < NT; ++t) {
+            const uint32_t tok = n0 + 16 * t + r;
+            uint32_t rt, rb;
+            tok_tb(P.res, tok < P.n ? tok : 0, rt, rb);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) resv[t][i] = (tok < P.n && m0 + 4 * g + i < P.m) ? dt_load(P.res, dt_index(P.res, m0 + 4 * g + i, rt, rb)) : 0.0f;
+        }
+    }
+
+    if (KIND == WRK_MAT_F16) {
+        // this wave's 32-k steps are wave, wave + NW, ...; eight steps' fragments are requested together (one memory round
+        // trip per batch instead of one per step: the LoRA projections were the stragglers of the multi-matrix launch)
+        const f16* wr = (const f16*)wrow;
+        constexpr int FB = 8;
+        const uint32_t nsteps = K >> 5, mine = wave < nsteps ? (nsteps - wave + NW - 1) / NW : 0;
+        for (uint32_t i0 = 0; i0 < mine; i0 += FB) {
+            f16x8 a[FB], bf[NT <= 2 ? NT : 1][FB];
+#pragma unroll
+            for (int u = 0; u < FB; ++u) {
+                const uint32_t k0 = 32 * (wave + NW * (i0 + u));
+                const bool ok = i0 + u < mine && k0 + 8 * g + 8 <= K;
+                a[u] = ok ? *(const f16x8*)(wr + k0 + 8 * g) : zero8;
+                if (NT <= 2) {
+#pragma unroll
+                    for (int t = 0; t < (NT <= 2 ? NT : 1); ++t) bf[t][u] = ok ? loadB(t, k0) : zero8;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < FB; ++u) {
+                const uint32_t k0 = 32 * (wave + NW * (i0 + u));
+                const bool ok = i0 + u < mine && k0 + 8 * g + 8 <= K;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const f16x8 bfr = NT <= 2 ? bf[NT <= 2 ? t : 0][u] : (ok ? loadB(t, k0) : zero8);
+                    total[t] = mfma16(a[u], bfr, total[t]);
+                }
             }
         }
     } else if (KIND == WRK_MAT_Q8_0) {
@@ -253,6 +288,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& P, float (*sh_tot)[N
             }
         };
         const uint32_t nmine = wave < nb ? (nb - wave + NW - 1) / NW : 0;      // blocks of this wave: wave, wave+NW, ...
+        WRK_STAMP(P.dbg, 1);
         // prefetch depth by regime: few tokens = few waves per CU = latency-bound (deep); many tokens = register-bound
         constexpr int WD = NT == 1 ? 4 : (NT == 2 ? 2 : 1);
         WBlk W[WD];
@@ -285,6 +321,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& P, float (*sh_tot)[N
         }
     }
 
+    WRK_STAMP(P.dbg, 2);                // this wave's blocks are multiplied
     // combine the four K slices
     if (wave > 0) {
 #pragma unroll
@@ -294,6 +331,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& P, float (*sh_tot)[N
     }
     __syncthreads();
     if (wave > 0) return;
+    WRK_STAMP(P.dbg, 3);                // partial tiles met in LDS
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -316,10 +354,11 @@ __device__ __forceinline__ void gemm_body(const GemmParams& P, float (*sh_tot)[N
             const uint32_t mr = m0 + 4 * g + i;
             if (mr >= P.m) continue;
             float o = act_apply(P.act, total[t][i] * P.scale);
-            if (P.has_res) { uint32_t rt, rb; tok_tb(P.res, tok, rt, rb); o = dt_round(P.out, o) + dt_load(P.res, dt_index(P.res, mr, rt, rb)); }
+            if (P.has_res) o = dt_round(P.out, o) + resv[t][i];
             dt_store(P.out, dt_index(P.out, mr, tt, bb), o);
         }
     }
+    WRK_STAMP(P.dbg, 4);
 }
 
 // One launch, several matrices: blockIdx.x -> job (like the matvec launches), kind dispatched at run time.
@@ -692,7 +731,7 @@ static bool gemm_ok(const MatJob& j, uint32_t n) {
 // path (n < 16, ROUND_F16, non-f16 / unaligned input, K % 32, Int8 / NF4): the caller falls back to the matvec kernels.
 static void fill_job(GemmParams& P, const MatJob& j, uint32_t n, uint32_t wg_begin) {
     P.w = j.w; P.kind = j.kind; P.k = j.k; P.m = j.m; P.row_bytes = j.row_bytes; P.act = j.act; P.n = n;
-    P.has_res = j.has_res; P.in = j.in; P.out = j.out; P.res = j.res; P.wg_begin = wg_begin; P.scale = j.scale;
+    P.has_res = j.has_res; P.in = j.in; P.out = j.out; P.res = j.res; P.wg_begin = wg_begin; P.scale = j.scale; P.dbg = j.dbg;
 }
 
 int matmul_mfma_multi(hipStream_t s, const MatJob* jobs, int njobs, int) {
