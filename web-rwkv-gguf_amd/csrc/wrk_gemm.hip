@@ -711,7 +711,7 @@ __global__ void __launch_bounds__(256) gemm_dec_kernel(const GemmBatch B) {
 
 // fewest stacked tokens sent to the matrix cores (tiles are padded to 16 tokens; below this the matvec kernels run)
 uint32_t gemm_min_tokens() {
-    static const uint32_t v = [] { const char* e = getenv("WRK_GEMM_MIN"); const int x = e ? atoi(e) : 4; return (uint32_t)(x < 2 ? 2 : x); }();     // measured: B=4 break-even, B=8 2x in favour of MFMA
+    static const uint32_t v = [] { const char* e = getenv("WRK_GEMM_MIN"); const int x = e ? atoi(e) : 2; return (uint32_t)(x < 2 ? 2 : x); }();     // measured (1.5B decode): 2 sequences break even, 3: 1.33 vs 1.79 ms, 8: 2x in favour of MFMA
     return v;
 }
 
@@ -760,7 +760,7 @@ int matmul_mfma_multi(hipStream_t s, const MatJob* jobs, int njobs, int) {
         // matrix x 128 tokens has only 64 tiles and is faster on the K-split kernel: 44 vs 74 us)
         const uint32_t tiles = ((j.m + TILE_ROWS - 1) / TILE_ROWS) * ((n + TILE_TOK - 1) / TILE_TOK);
         const bool tile = use_tile && n >= 48 && (j.kind == WRK_MAT_Q4_K || j.kind == WRK_MAT_Q5_K || j.kind == WRK_MAT_F16) && j.m >= 64 &&
-                          j.in.shape[2] == 1 && (tiles >= 128 || j.k <= 2560);      // <= 10 blocks per wave: the serial walk is short anyway
+                          j.in.shape[2] == 1 && (tiles >= 96 || (j.k <= 2560 && tiles >= 64));     // enough workgroups, or a short serial walk
         if (tile) { fill_job(T.jobs[T.njobs++], j, n, twg); twg += (j.m + TILE_ROWS - 1) / TILE_ROWS; }
         else { fill_job(B.jobs[B.njobs++], j, n, wg); wg += (j.m + 15) / 16; kmax = j.k > kmax ? j.k : kmax; }
     }
