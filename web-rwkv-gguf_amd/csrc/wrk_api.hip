@@ -39,7 +39,6 @@ int32_t wrk_ctx_destroy(wrk_ctx* ctx) {
     hipStreamSynchronize(ctx->stream);
     hipStreamSynchronize(ctx->read_stream);
     if (ctx->staging) hipHostFree(ctx->staging);
-    if (ctx->xsum) hipFree(ctx->xsum);
     hipEventDestroy(ctx->read_event);
     hipStreamDestroy(ctx->read_stream);
     hipStreamDestroy(ctx->stream);

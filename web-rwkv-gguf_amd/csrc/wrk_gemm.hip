@@ -785,6 +785,6 @@ int matmul_mfma_multi(hipStream_t s, const MatJob* jobs, int njobs, int) {
     return 0;
 }
 
-int matmul_mfma(hipStream_t s, const MatJob& j, int num_cu, float*, size_t) { return matmul_mfma_multi(s, &j, 1, num_cu); }
+int matmul_mfma(hipStream_t s, const MatJob& j, int num_cu) { return matmul_mfma_multi(s, &j, 1, num_cu); }
 
 }  // namespace wrk

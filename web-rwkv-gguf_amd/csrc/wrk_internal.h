@@ -24,8 +24,6 @@ struct wrk_ctx {
     int num_cu = 256;
     void* staging = nullptr;            // pinned host staging for wrk_buf_write
     size_t staging_bytes = 0;
-    float* xsum = nullptr;              // GEMM scratch: per-32 input sums [tokens][K/32]
-    size_t xsum_cap = 0;
 };
 
 struct wrk_buf {
@@ -181,9 +179,8 @@ struct MatJob {
 uint32_t matvec_num_wg(const MatJob* jobs, int njobs, int num_cu, uint32_t* rows_per_wg);
 // dry_run: classify only (0 = a launch would honour every job's prologue / carry request, -3 = it cannot)
 int matvec(hipStream_t s, const MatJob* jobs, int njobs, int num_cu, bool dry_run = false);
-// MFMA dequant-GEMM (wrk_gemm.hip); -2 = not applicable (caller uses the matvec kernels).  xsum_scratch: device
-// f32 buffer of at least tokens * K/32 elements (only the K4 kinds use it)
-int matmul_mfma(hipStream_t s, const MatJob& job, int num_cu, float* unused = nullptr, size_t unused_cap = 0);
+// MFMA dequant-GEMM (wrk_gemm.hip); -2 = not applicable (caller uses the matvec kernels)
+int matmul_mfma(hipStream_t s, const MatJob& job, int num_cu);
 // several matrices x the same tokens in ONE launch (-2 if any job is not for the MFMA path)
 int matmul_mfma_multi(hipStream_t s, const MatJob* jobs, int njobs, int num_cu);
 uint32_t gemm_min_tokens();

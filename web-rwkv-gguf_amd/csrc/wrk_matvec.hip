@@ -6,18 +6,22 @@
 //   matmul_vec_q5k/q6k/q8_0 ops.rs:1543-1948 -- semantics from gguf.rs:11-37,149-274 (SURVEY F3:
 //   the Q5_K/Q6_K/Q8_0 shaders are defective; the CPU dequantisers are canonical)
 //
-// Design (DESIGN.md "matvec"): the kernel is HBM-bound, so everything is arranged around 16-byte
-// coalesced weight loads straight into VGPRs:
+//   matmul_vec_int8 / nf4   ops.rs:791-991   + shaders/matmul_vec_int8.wgsl, matmul_vec_nf4.wgsl (web-rwkv's own formats)
+//
+// Design: everything is arranged around 16-byte coalesced weight loads straight into VGPRs:
 //   * blocks are re-laid-out per row at upload (repack_rows) into 16-byte aligned planes
 //     (quants | high bits | scales/header), so lane L of a wave reads the L-th 16-byte chunk of the
 //     quant plane: one global_load_dwordx4 per lane covers 1 KiB contiguous per wave-instruction;
 //   * one wave64 owns a row; 4 waves (256 threads) per workgroup;
-//   * the input vector(s) are staged once per workgroup in LDS as f16, together with the per-16
-//     partial sums that carry the K-quant "min" term:  sum_l (d*sc*q_l - dmin*m) x_l
-//       = d*sc * sum_l q_l x_l  -  dmin*m * sum_l x_l ;
-//   * integer codes become f16 by byte-permute into 0x6400|q (= 1024+q, exact) and one packed
-//     subtract, then v_dot2_f32_f16 accumulates exact f16*f16 products in f32;
-//   * wave64 butterfly reduction, fused activation, store in the output buffer's dtype.
+//   * ONE input vector (decode): matvec_reg_kernel -- the inputs a lane multiplies are the same for every row and
+//     live in registers; optional fused LN + token-shift prologue (computed once per workgroup, shared through LDS),
+//     fused residual / gate / state-carry / arg-max epilogues; long rows split K over the 4 waves;
+//   * 2..8 input vectors: matvec_kernel<NB> stages them in LDS as f16 with per-16 partial sums;
+//   * the K-quant "min" term is factored:  sum_l (d*sc*q_l - dmin*m) x_l = d*sc * sum_l q_l x_l - dmin*m * sum_l x_l ;
+//   * integer codes become f16 with one byte-permute: a code in the low mantissa bits of an f16 is the subnormal
+//     code * 2^-24 (exact; the 2^24 is folded into the group scale), then v_dot2_f32_f16 accumulates exact
+//     f16*f16 products in f32;
+//   * wave64 DPP reduction, fused activation, store in the output buffer's dtype.
 // WRK_MATRIX_ROUND_F16 instead rounds every dequantised weight to f16 first, reproducing the
 // reference at HEAD (weights dequantised to f16 on the CPU at load, gguf.rs:95-274).
 #include <algorithm>

@@ -65,13 +65,6 @@ int32_t wrk_v6_model::ensure_scratch(uint32_t T, uint32_t NH) {
     s.cursors = (uint32_t*)(b + o_cur); s.tokens = (uint32_t*)(b + o_tok); s.headers = (uint32_t*)(b + o_hdr); s.argmax = (uint32_t*)(b + o_arg);
     s.counter = (uint32_t*)(b + o_cnt);
     scratch_tokens = nt; scratch_headers = nh;
-    const size_t kmax = F > D ? F : D, need = (size_t)nt * (kmax / 32 + 1);
-    if (nt >= 16 && need > ctx->xsum_cap) {
-        if (ctx->xsum) hipFree(ctx->xsum);
-        ctx->xsum = nullptr; ctx->xsum_cap = 0;
-        WRK_HIP(ctx, hipMalloc((void**)&ctx->xsum, need * 4));
-        ctx->xsum_cap = need;
-    }
     return WRK_OK;
 }
 

@@ -60,17 +60,6 @@ int32_t wrk_v7_model::ensure_scratch(uint32_t T, uint32_t NH) {
     s.counter = (uint32_t*)(b + o_cnt);
     scratch_tokens = nt;
     scratch_headers = nh;
-    // GEMM scratch (per-32 input sums) for chunks of >= 16 tokens
-    {
-        const size_t kmax = d.num_hidden > d.num_emb ? d.num_hidden : d.num_emb;
-        const size_t need = (size_t)nt * (kmax / 32 + 1);
-        if (nt >= 16 && need > ctx->xsum_cap) {
-            if (ctx->xsum) hipFree(ctx->xsum);
-            ctx->xsum = nullptr; ctx->xsum_cap = 0;
-            WRK_HIP(ctx, hipMalloc((void**)&ctx->xsum, need * 4));
-            ctx->xsum_cap = need;
-        }
-    }
     // arg-max partials of the head matvec: one (value, index) per workgroup and header row
     {
         wrk::MatJob hj = mj(head, make_dense(s.head_x, WRK_F16, d.num_emb, nh), make_dense(s.head_o, WRK_F32, d.num_vocab, nh), 0);
