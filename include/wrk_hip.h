@@ -308,7 +308,9 @@ int32_t wrk_v6_model_destroy(wrk_v6_model* model);
 size_t wrk_v6_model_token_bytes(const wrk_v6_model* model, uint32_t num_batch);
 /* v6::Bundle::new state allocation; the handle type is shared with V7 (identical layout) */
 int32_t wrk_v6_state_create(wrk_ctx* ctx, const wrk_v6_model* model, uint32_t num_batch, wrk_v7_state** out);
-/* as wrk_v7_infer / wrk_v7_generate_greedy (mode is ignored: op-by-op kernels) */
+/* as wrk_v7_infer / wrk_v7_generate_greedy.  mode 1: jobs whose tokens are one per sequence (decode) run the fused
+ * 7-launch layer (LN prologues in the consumer matvec, v6_mix / v6_head kernels, gated ffn epilogue); everything else,
+ * and mode 0, runs one kernel per reference op (v6.rs:701-958) */
 int32_t wrk_v6_infer(wrk_ctx* ctx, wrk_v6_model* model, wrk_v7_state* state,
                      const uint32_t* tokens, const uint16_t* emb_rows, const uint32_t* cursors, uint32_t num_token,
                      const uint32_t* headers, uint32_t num_header, float* logits, uint32_t* argmax, uint32_t mode);
