@@ -177,11 +177,13 @@ def make_model_gguf(name, seed=42):
         f32(p + "time_mix_r_k.weight", [D], nrm(D, 0.3))
         f32(p + "time_mix_k_k.weight", [D], 1 + nrm(D, 0.2)); f32(p + "time_mix_k_a.weight", [D], 1 + nrm(D, 0.2))
         f32(p + "time_mix_ln.weight", [D], 1 + nrm(D, 0.1)); f32(p + "time_mix_ln.bias", [D], nrm(D, 0.05))
+        # branch outputs are scaled down (as trained models' are relative to the residual stream): with unit-gain random
+        # branches a 24-layer stack amplifies one f16 rounding flip into O(1) logit changes and nothing could be compared
         for nm in ("key", "value", "receptance", "output"):
-            tensors.append((p + f"time_mix_{nm}.weight", [D, D], 12, _q4k_blocks(rng, D * D, 1.0 / np.sqrt(D))))
+            tensors.append((p + f"time_mix_{nm}.weight", [D, D], 12, _q4k_blocks(rng, D * D, (0.1 if nm == "output" else 1.0) / np.sqrt(D))))
         f32(p + "channel_mix_lerp_k.weight", [D], rng.random(D, dtype=np.float32))
         tensors.append((p + "channel_mix_key.weight", [D, F], 12, _q4k_blocks(rng, F * D, 1.0 / np.sqrt(D))))
-        tensors.append((p + "channel_mix_value.weight", [F, D], 12, _q4k_blocks(rng, D * F, 0.5 / np.sqrt(F))))
+        tensors.append((p + "channel_mix_value.weight", [F, D], 12, _q4k_blocks(rng, D * F, 0.05 / np.sqrt(F))))
 
     meta = [("general.architecture", 8, "rwkv7"), ("general.alignment", 4, 32), ("rwkv7.wkv.head_size", 4, 64),
             ("rwkv7.block_count", 4, L), ("rwkv7.embedding_length", 4, D), ("rwkv7.feed_forward_length", 4, F)]
