@@ -166,7 +166,8 @@ size_t wrk_matrix_stream_bytes(const wrk_matrix* mat);
  * reference does (TensorError -> WRK_E_ARG). */
 
 /* Matrix::matmul_op (matrix.rs:185-209): output[M, T, B] = act(W[K, M] . input[K, T, B]).
- * turbo != 0 selects the GEMM kernel (T % 32 == 0 in the reference); sparse = matmul_op_sparse */
+ * turbo != 0 selects the MFMA GEMM kernels for >= 2 stacked tokens (the reference takes T % 32 == 0 there; here token
+ * tiles are padded, so any count works); sparse = matmul_op_sparse */
 int32_t wrk_op_matmul(wrk_ctx* ctx, const wrk_matrix* mat, const wrk_tensor* input, const wrk_tensor* output,
                       uint32_t act, int32_t turbo, int32_t sparse);
 /* TensorOp::layer_norm (ops.rs:407-454): x[C, T, B] in place, w/b f16 [C] */

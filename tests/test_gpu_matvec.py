@@ -96,13 +96,13 @@ def test_matrix_create_rejects_bad_input(ctx):
         mat.matmul_op(ctx.zeros([32, 1, 1]), ctx.zeros([4, 1, 1]))            # K mismatch
 
 
-# ------------------------------------------------------------------ MFMA dequant-GEMM (turbo path, >= 16 tokens)
+# ------------------------------------------------------------------ MFMA dequant-GEMM (turbo path; tiles padded to 16 tokens)
 GEMM_CASES = [("Q4_K", 2048, 100), ("Q4_K", 512, 64), ("Q5_K", 1024, 48), ("Q6_K", 512, 130), ("Q6_K", 2048, 33),
               ("Q8_0", 96 * 2, 40), ("Q8_0", 1024, 64), ("F16", 96, 256), ("F16", 2048, 70), ("F32", 256, 64)]
 
 
 @pytest.mark.parametrize("kind,k,m", GEMM_CASES)
-@pytest.mark.parametrize("T,B", [(16, 1), (32, 1), (37, 1), (128, 1), (8, 3)])
+@pytest.mark.parametrize("T,B", [(2, 1), (3, 1), (9, 1), (16, 1), (32, 1), (37, 1), (128, 1), (8, 3)])
 def test_gemm_matches_oracle(ctx, kind, k, m, T, B):
     """Matrix::matmul_op(turbo=true) (matrix.rs:185-196) on the matrix cores: exact-weight f32 contraction."""
     raw = make(kind, k, m, k * 3 + m)

@@ -403,7 +403,7 @@ int32_t wrk_op_matmul(wrk_ctx* ctx, const wrk_matrix* mat, const wrk_tensor* inp
     j.scale = mat->out_scale;
     int rc = -2;
     const size_t ntok = (size_t)input->view.shape[1] * input->view.shape[2];
-    if (turbo && ntok >= 16) rc = wrk::matmul_mfma(ctx->stream, j, ctx->num_cu);
+    if (turbo && ntok >= 2) rc = wrk::matmul_mfma(ctx->stream, j, ctx->num_cu);     // tiles are padded to 16 tokens
     if (rc == -2) rc = wrk::matvec(ctx->stream, &j, 1, ctx->num_cu);
     WRK_ARG(ctx, rc == 0, "matmul: launch configuration rejected");
     WRK_LAUNCH_CHECK(ctx);
