@@ -275,28 +275,30 @@ __device__ __forceinline__ uint32_t num_chunks(uint32_t k, uint32_t kpad) {
 
 template <int KIND>
 __device__ __forceinline__ Raw load_raw(const uint8_t* __restrict__ row, uint32_t k, uint32_t c, uint32_t phase = 0) {
+    // every offset is 32-bit and relative to the (wave-uniform) row pointer: with a scalar base the loads take the
+    // `saddr + voffset` form and the per-lane 64-bit address arithmetic disappears (it was ~1/4 of the kernel's VALU work)
     Raw r;
-    r.w = __builtin_nontemporal_load((const u32x4*)(row + (size_t)c * 16));
+    r.w = __builtin_nontemporal_load((const u32x4*)(row + c * 16u));
     const uint32_t nb = k >> 8, b = c >> 3;
     if (KIND == WRK_MAT_Q4_K) {
-        r.a.x = *(const uint32_t*)(row + (size_t)nb * 128 + (size_t)b * 4);
-        r.a.y = *(const uint32_t*)(row + (size_t)nb * 132 + (size_t)b * 16 + ((c & 7u) >> 1) * 4);
+        r.a.x = *(const uint32_t*)(row + (nb * 128u + b * 4u));
+        r.a.y = *(const uint32_t*)(row + (nb * 132u + b * 16u + ((c & 7u) >> 1) * 4u));
     } else if (KIND == WRK_MAT_Q5_K) {
-        r.a = *(const u32x4*)(row + (size_t)nb * 128 + (size_t)b * 32 + (c & 1u) * 16);
-        r.b.x = *(const uint32_t*)(row + (size_t)nb * 160 + (size_t)b * 4);
-        r.b.y = *(const uint32_t*)(row + (size_t)nb * 164 + (size_t)b * 16 + ((c & 7u) >> 1) * 4);
+        r.a = *(const u32x4*)(row + (nb * 128u + b * 32u + (c & 1u) * 16u));
+        r.b.x = *(const uint32_t*)(row + (nb * 160u + b * 4u));
+        r.b.y = *(const uint32_t*)(row + (nb * 164u + b * 16u + ((c & 7u) >> 1) * 4u));
     } else if (KIND == WRK_MAT_Q6_K) {
         const uint32_t sub = c & 7u, n128 = sub >> 2, part = (sub >> 1) & 1u, l0 = (sub & 1u) * 16u;
-        r.a = *(const u32x4*)(row + (size_t)nb * 128 + (size_t)b * 64 + n128 * 32 + l0);
-        const uint8_t* scp = row + (size_t)nb * 192 + (size_t)b * 16 + n128 * 8 + (l0 >> 4) + part * 2;
-        const uint32_t dbits = *(const uint16_t*)(row + (size_t)nb * 208 + (size_t)b * 2);
+        r.a = *(const u32x4*)(row + (nb * 128u + b * 64u + n128 * 32u + l0));
+        const uint8_t* scp = row + (nb * 192u + b * 16u + n128 * 8u + (l0 >> 4) + part * 2u);
+        const uint32_t dbits = *(const uint16_t*)(row + (nb * 208u + b * 2u));
         r.b.x = (uint32_t)scp[0] | ((uint32_t)scp[4] << 8) | (dbits << 16);
     } else if (KIND == WRK_MAT_Q8_0) {
-        r.a.x = *(const uint16_t*)(row + (size_t)k + (size_t)(c >> 1) * 2);
+        r.a.x = *(const uint16_t*)(row + (k + (c >> 1) * 2u));
     } else if (KIND == WRK_MAT_INT8) {
-        r.a.x = *(const uint32_t*)(row + (size_t)k + (size_t)((c + phase) >> 3) * 4);   // (min, max) f16 of the 128-block
+        r.a.x = *(const uint32_t*)(row + (k + ((c + phase) >> 3) * 4u));   // (min, max) f16 of the 128-block
     } else if (KIND == WRK_MAT_NF4) {
-        r.a.x = *(const uint16_t*)(row + (size_t)(k >> 1) + (size_t)(c >> 1) * 2);   // absmax f16 of the 64-block
+        r.a.x = *(const uint16_t*)(row + ((k >> 1) + (c >> 1) * 2u));     // absmax f16 of the 64-block
     }
     return r;
 }
@@ -365,8 +367,11 @@ __device__ __forceinline__ void decode_raw(const Raw& r, uint32_t c, Group& lo, 
     } else {
         const u32x4 qh = r.a;
         const uint32_t s0 = 2 * j, s1 = 2 * j + 1;
-#define Q5LO(W, H) (((W) & 0x0f0f0f0fu) | ((((H) >> s0) & 0x01010101u) << 4))
-#define Q5HI(W, H) ((((W) >> 4) & 0x0f0f0f0fu) | ((((H) >> s1) & 0x01010101u) << 4))
+        // bit s of every byte of H -> bit 4 of the same byte with ONE rotate (by s - 4 mod 32: the bit that lands on
+        // position 8b + 4 is always 8b + s) and one mask; v_and_or_b32 then merges it with the nibble
+        const uint32_t r0 = (s0 + 28u) & 31u, r1 = (s1 + 28u) & 31u;
+#define Q5LO(W, H) (((W) & 0x0f0f0f0fu) | (__builtin_amdgcn_alignbit((H), (H), r0) & 0x10101010u))
+#define Q5HI(W, H) ((((W) >> 4) & 0x0f0f0f0fu) | (__builtin_amdgcn_alignbit((H), (H), r1) & 0x10101010u))
         bytes_to_h2(Q5LO(w.x, qh.x), lo.q[0], lo.q[1]);
         bytes_to_h2(Q5LO(w.y, qh.y), lo.q[2], lo.q[3]);
         bytes_to_h2(Q5LO(w.z, qh.z), lo.q[4], lo.q[5]);
@@ -672,6 +677,8 @@ __device__ __forceinline__ void matvec_body_reg(const JobDev& J, unsigned char* 
     const uint32_t cbase = KS == 1 ? lane : lane + 64 * wave;
     auto row_of = [&](uint32_t ri) { return KS == 1 ? r0 + wave + 4 * ri : r0 + ri; };
 
+    // (tried, round 1: refilling half a batch while the other half is multiplied, for waves that own more than 4 rows.
+    // It made every launch slower -- RWKV-6 7B decode 3.00 -> 3.30 ms -- so a batch is issued as a whole.)
     Raw raw[RB][XI];
     auto issue = [&](uint32_t ri0) {
 #pragma unroll
@@ -680,7 +687,7 @@ __device__ __forceinline__ void matvec_body_reg(const JobDev& J, unsigned char* 
             for (int ci = 0; ci < XI; ++ci) {
                 const uint32_t c = cbase + CSTEP * ci;
                 if (ri0 + rb < nrows && c < nch) {
-                    const uint32_t rr = row_of(ri0 + rb);
+                    const uint32_t rr = (uint32_t)__builtin_amdgcn_readfirstlane((int)row_of(ri0 + rb));     // wave-uniform: scalar base
                     // Int8 blocks run over the flattened matrix: the row starts `phase` 16-element chunks into a block
                     const uint32_t phase = KIND == WRK_MAT_INT8 ? (uint32_t)((((size_t)rr * K) >> 4) & 7u) : 0u;
                     raw[rb][ci] = load_raw<KIND>(J.w + (size_t)rr * J.row_bytes, K, c, phase);
@@ -1007,7 +1014,8 @@ uint32_t matvec_num_wg(const MatJob* jobs, int njobs, int num_cu, uint32_t* rows
     uint32_t total_rows = 0;
     for (int j = 0; j < njobs; ++j) total_rows += jobs[j].m;
     // rows per workgroup: aim at >= 4 workgroups per CU, 4..32 rows (1..8 per wave)
-    uint32_t rpw = (total_rows + (uint32_t)num_cu * 4 - 1) / ((uint32_t)num_cu * 4);
+    static const uint32_t per_cu = [] { const char* e = getenv("WRK_WG_PER_CU"); const int v = e ? atoi(e) : 4; return (uint32_t)(v < 1 ? 1 : (v > 16 ? 16 : v)); }();
+    uint32_t rpw = (total_rows + (uint32_t)num_cu * per_cu - 1) / ((uint32_t)num_cu * per_cu);
     rpw = (rpw + 3) & ~3u;
     rpw = rpw < 4 ? 4 : (rpw > 32 ? 32 : rpw);
     // a launch with the LN prologue pays ~6 vector loads + two block reductions per workgroup: amortise over more rows
