@@ -664,7 +664,7 @@ template <int KIND, bool R16, int XI, int KS>
 __device__ __forceinline__ void matvec_body_reg(const JobDev& J, unsigned char* smem) {
     // rows in flight per wave: everything a wave owns (<= 4 rows for <= 16 rows per workgroup) goes out in ONE round
     // trip -- the in-kernel timeline (WRK_TIMING) showed a second trip costs 1.2 us, a third of the kernel
-    constexpr int RB = 4;
+    constexpr int RB = 4;       // (2 rows for the XI = 2 kernels: fewer VGPRs, 3 waves per SIMD -- measured 2.5 % slower)
     static_assert(KS == 1 || XI <= 2, "K-split: one or two chunk iterations per wave (K <= 16384 for the block kinds)");
     constexpr uint32_t CSTEP = KS == 1 ? 64u : 256u;       // chunk stride between a lane's iterations
     const uint32_t K = J.k;
