@@ -1017,7 +1017,8 @@ uint32_t matvec_num_wg(const MatJob* jobs, int njobs, int num_cu, uint32_t* rows
     static const uint32_t per_cu = [] { const char* e = getenv("WRK_WG_PER_CU"); const int v = e ? atoi(e) : 4; return (uint32_t)(v < 1 ? 1 : (v > 16 ? 16 : v)); }();
     uint32_t rpw = (total_rows + (uint32_t)num_cu * per_cu - 1) / ((uint32_t)num_cu * per_cu);
     rpw = (rpw + 3) & ~3u;
-    rpw = rpw < 4 ? 4 : (rpw > 32 ? 32 : rpw);
+    static const uint32_t rpw_min = [] { const char* e = getenv("WRK_RPW_MIN"); const int v = e ? atoi(e) : 4; return (uint32_t)(v < 4 ? 4 : (v > 32 ? 32 : v)) & ~3u; }();
+    rpw = rpw < rpw_min ? rpw_min : (rpw > 32 ? 32 : rpw);
     // a launch with the LN prologue pays ~6 vector loads + two block reductions per workgroup: amortise over more rows
     static const uint32_t pro_rpw = [] { const char* e = getenv("WRK_PRO_RPW"); const int v = e ? atoi(e) : 16; return (uint32_t)(v < 4 ? 4 : (v > 32 ? 32 : v)) & ~3u; }();
     for (int j = 0; j < njobs; ++j)

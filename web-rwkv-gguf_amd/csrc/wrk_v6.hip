@@ -639,7 +639,7 @@ int32_t wrk_v6_generate_greedy(wrk_ctx* ctx, wrk_v6_model* m, wrk_v7_state* st, 
         return WRK_OK;
     };
     wrk_program* prog = nullptr;
-    const auto key = std::make_tuple((const void*)st, B, mode);
+    const auto key = std::make_tuple(st->uid, B, mode);
     if (!eager) {
         auto it = m->graphs.find(key);
         if (it != m->graphs.end()) prog = it->second;

@@ -1,5 +1,6 @@
 // Internal definitions of the RWKV-7 model / state handles.
 #pragma once
+#include <atomic>
 #include <map>
 #include <tuple>
 #include <vector>
@@ -8,6 +9,10 @@
 #include "wrk_device.h"
 
 struct wrk_v7_state {
+    // captured graphs bake the state's addresses and strides in: they are keyed by this id, never reused, rather than by
+    // the handle's address (a destroyed state's address can come back with another num_batch)
+    const void* uid = next_uid();
+    static const void* next_uid() { static std::atomic<uintptr_t> n{1}; return (const void*)(n.fetch_add(1) << 4); }
     wrk_ctx* ctx = nullptr;
     uint32_t num_layer = 0, num_emb = 0, head_size = 0, num_batch = 0;
     float* data = nullptr;      // [L][B][S+2][D] f32 == L tensors [D, S+2, B] (v7.rs:514-527)

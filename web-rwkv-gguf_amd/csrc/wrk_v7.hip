@@ -398,7 +398,7 @@ int32_t wrk_v7_infer(wrk_ctx* ctx, wrk_v7_model* m, wrk_v7_state* st, const uint
     else {
         const uint32_t flags = 16u | (fused ? 1u : 0u) | (identity ? 2u : 0u) | (tokens ? 4u : 0u) | ((NH && argmax) ? 8u : 0u) |
                                (fused ? (cursors[0] & 0xffu) << 8 : 0u);
-        const wrk_v7_model::GraphKey key{st, T, flags, NH};
+        const wrk_v7_model::GraphKey key{st->uid, T, flags, NH};
         wrk_program* prog = nullptr;
         auto it = m->graphs.find(key);
         if (it != m->graphs.end()) prog = it->second;
@@ -464,7 +464,7 @@ int32_t wrk_v7_generate_greedy(wrk_ctx* ctx, wrk_v7_model* m, wrk_v7_state* st, 
         wrk::advance_tokens(ctx->stream, m->s.argmax, m->s.tokens, m->history, m->s.counter, B);
         return WRK_OK;
     };
-    const wrk_v7_model::GraphKey key{st, B, mode};
+    const wrk_v7_model::GraphKey key{st->uid, B, mode};
     wrk_program* prog = nullptr;
     if (!eager) {
         auto it = m->graphs.find(key);
