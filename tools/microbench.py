@@ -15,7 +15,7 @@ import ctypes as C  # noqa: E402
 
 import wrk  # noqa: E402
 
-BLOCK = {"Q4_K": (256, 144), "Q5_K": (256, 176), "Q6_K": (256, 210), "Q8_0": (32, 34), "F16": (1, 2), "INT8": (128, 132)}
+BLOCK = {"Q4_K": (256, 144), "Q5_K": (256, 176), "Q6_K": (256, 210), "Q8_0": (32, 34), "F16": (1, 2), "INT8": (128, 132), "NF4": (64, 34)}
 
 
 def run(ctx, kind, k, m, nin=1, reps=200, copies=4, turbo=False):
@@ -25,6 +25,10 @@ def run(ctx, kind, k, m, nin=1, reps=200, copies=4, turbo=False):
     for _ in range(copies):      # several copies so consecutive launches do not re-read the same bytes from cache
         if kind == "INT8":      # codes ++ (min, max) f16 per 128 flattened elements
             raw = np.concatenate([rng.integers(0, 256, k * m, dtype=np.uint8), np.tile(np.array([-0.1, 0.1], np.float16).view(np.uint8), k * m // 128)])
+            mats.append(wrk.Matrix(ctx, kind, k, m, raw))
+            continue
+        if kind == "NF4":       # nibbles ++ absmax f16 per 64 flattened elements
+            raw = np.concatenate([rng.integers(0, 256, k * m // 2, dtype=np.uint8), np.tile(np.array([0.1], np.float16).view(np.uint8), k * m // 64)])
             mats.append(wrk.Matrix(ctx, kind, k, m, raw))
             continue
         raw = rng.integers(0, 256, k * m // be * bb, dtype=np.uint8)
@@ -65,7 +69,7 @@ if __name__ == "__main__":
     ctx = wrk.Context(0)
     shapes = [("Q4_K", 2048, 2048), ("Q4_K", 2048, 8192), ("Q4_K", 8192, 2048), ("Q6_K", 2048, 65536), ("F16", 2048, 65536),
               ("Q4_K", 2560, 2560), ("Q8_0", 4096, 4096), ("Q5_K", 4096, 4096), ("F16", 2048, 96), ("F16", 96, 2048),
-              ("INT8", 4096, 4096), ("Q5_K", 14336, 4096), ("Q5_K", 4096, 14336)]
+              ("INT8", 4096, 4096), ("NF4", 4096, 4096), ("Q5_K", 14336, 4096), ("Q5_K", 4096, 14336)]
     if len(sys.argv) > 1:
         shapes = [s for s in shapes if s[0] in sys.argv[1:]]
     for kind, k, m in shapes:

@@ -593,6 +593,10 @@ __device__ __forceinline__ void matvec_body(const JobDev& J, unsigned char* smem
             }
         }
     }
+    // NF4 / SF4: the 16 f32 levels go to LDS once per workgroup (a per-element table read from global memory made this
+    // kernel 27x slower than Int8: 140 us for a 4096 x 4096 matrix)
+    float* lut = xsum + (size_t)NB * (kpad >> 4);
+    if (KIND == WRK_MAT_NF4 && tid < 16) lut[tid] = J.aux[tid];
     __syncthreads();
 
     float best_v[NB];
@@ -611,7 +615,7 @@ __device__ __forceinline__ void matvec_body(const JobDev& J, unsigned char* smem
             if (c < nch) {
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb)
-                    if (ri0 + rb < nrows) dot_raw<KIND, R16, NB>(raw[rb], c, xs, xsum, kpad, acc[rb], J.aux);
+                    if (ri0 + rb < nrows) dot_raw<KIND, R16, NB>(raw[rb], c, xs, xsum, kpad, acc[rb], lut);
             }
         }
 #pragma unroll
@@ -910,6 +914,10 @@ static matvec_fn pick_kernel(int ka, int kb, bool r16) {
     PAIR(WRK_MAT_Q6_K)
     PAIR(WRK_MAT_Q8_0)
 #undef PAIR
+    // web-rwkv's own formats never round to f16; a dedicated kernel per kind (the all-kinds catch-all allocates registers
+    // for every decoder: NF4 ran at 65 GB/s in it)
+    if (ka == WRK_MAT_NF4) return kb == ka ? (matvec_fn)matvec_kernel<NB, WRK_MAT_NF4, WRK_MAT_NF4, false> : (matvec_fn)matvec_kernel<NB, WRK_MAT_NF4, WRK_MAT_F16, false>;
+    if (ka == WRK_MAT_INT8) return kb == ka ? (matvec_fn)matvec_kernel<NB, WRK_MAT_INT8, WRK_MAT_INT8, false> : (matvec_fn)matvec_kernel<NB, WRK_MAT_INT8, WRK_MAT_F16, false>;
     if (ka == WRK_MAT_F16) return pick_r16<NB, WRK_MAT_F16, WRK_MAT_F16>(false);
     return (matvec_fn)matvec_kernel<NB, -1, -1, false>;
 }
@@ -1059,7 +1067,7 @@ int matvec(hipStream_t s, const MatJob* jobs, int njobs, int num_cu, bool dry_ru
     // pick inputs-per-pass: LDS budget 144 KiB
     int nb = ntok >= 8 ? 8 : (ntok >= 4 ? 4 : (ntok >= 2 ? 2 : 1));
     while (nb > 1 && (size_t)nb * kpad * 2 + (size_t)nb * (kpad >> 4) * 4 > 144 * 1024) nb >>= 1;
-    size_t smem = (size_t)nb * kpad * 2 + (size_t)nb * (kpad >> 4) * 4;
+    size_t smem = (size_t)nb * kpad * 2 + (size_t)nb * (kpad >> 4) * 4 + 64;      // inputs | per-16 sums | NF4 level table
     if (smem < 256) smem = 256;
     const uint32_t groups = (ntok + nb - 1) / nb;
     switch (nb) {
