@@ -147,7 +147,12 @@ def make_model_gguf_v6(name, seed=42):
     return _write_gguf(tensors, meta)
 
 
-def make_model_gguf(name, seed=42):
+def use_more_bits(i_layer, n_layer):
+    """llama.cpp's Q4_K_M recipe: attn_v and ffn_down get Q6_K in the first and last eighth and every third layer between."""
+    return i_layer < n_layer // 8 or i_layer >= 7 * n_layer // 8 or (i_layer - n_layer // 8) % 3 == 2
+
+
+def make_model_gguf(name, seed=42, mixed=False):
     if name in CONFIGS_V6:
         return make_model_gguf_v6(name, seed)
     L, D, F, V, rw, ra, rv, rg = CONFIGS[name]
@@ -179,11 +184,19 @@ def make_model_gguf(name, seed=42):
         f32(p + "time_mix_ln.weight", [D], 1 + nrm(D, 0.1)); f32(p + "time_mix_ln.bias", [D], nrm(D, 0.05))
         # branch outputs are scaled down (as trained models' are relative to the residual stream): with unit-gain random
         # branches a 24-layer stack amplifies one f16 rounding flip into O(1) logit changes and nothing could be compared
+        q6 = mixed and use_more_bits(l, L)
         for nm in ("key", "value", "receptance", "output"):
-            tensors.append((p + f"time_mix_{nm}.weight", [D, D], 12, _q4k_blocks(rng, D * D, (0.1 if nm == "output" else 1.0) / np.sqrt(D))))
+            std = (0.1 if nm == "output" else 1.0) / np.sqrt(D)
+            if q6 and nm == "value":
+                tensors.append((p + "time_mix_value.weight", [D, D], 14, _q6k_blocks(rng, D * D, std)))
+            else:
+                tensors.append((p + f"time_mix_{nm}.weight", [D, D], 12, _q4k_blocks(rng, D * D, std)))
         f32(p + "channel_mix_lerp_k.weight", [D], rng.random(D, dtype=np.float32))
         tensors.append((p + "channel_mix_key.weight", [D, F], 12, _q4k_blocks(rng, F * D, 1.0 / np.sqrt(D))))
-        tensors.append((p + "channel_mix_value.weight", [F, D], 12, _q4k_blocks(rng, D * F, 0.05 / np.sqrt(F))))
+        if q6:
+            tensors.append((p + "channel_mix_value.weight", [F, D], 14, _q6k_blocks(rng, D * F, 0.05 / np.sqrt(F))))
+        else:
+            tensors.append((p + "channel_mix_value.weight", [F, D], 12, _q4k_blocks(rng, D * F, 0.05 / np.sqrt(F))))
 
     meta = [("general.architecture", 8, "rwkv7"), ("general.alignment", 4, 32), ("rwkv7.wkv.head_size", 4, 64),
             ("rwkv7.block_count", 4, L), ("rwkv7.embedding_length", 4, D), ("rwkv7.feed_forward_length", 4, F)]
@@ -233,6 +246,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="independent streams per GPU")
     ap.add_argument("--mode", type=int, default=1, help="1 = fused decode kernels, 0 = one kernel per reference op")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mixed", action="store_true", help="llama.cpp Q4_K_M tensor mix: Q6_K for attn value / ffn value in about half of the layers")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -249,7 +263,7 @@ def main():
     from wrk import replicas
     group = replicas.ReplicaGroup(dist, device="cuda" if dist is not None else None)
     t0 = time.time()
-    gg = make_model_gguf(args.model, seed=42 + rank)
+    gg = make_model_gguf(args.model, seed=42 + rank, mixed=args.mixed) if args.model not in CONFIGS_V6 else make_model_gguf(args.model, seed=42 + rank)
     ctx = wrk.Context(local_rank)
     reader = wrk.GgufReader(gg)
     runtime = wrk.Runtime(ctx, reader, num_batch=args.batch, weights=wrk.WEIGHTS_INLINE)

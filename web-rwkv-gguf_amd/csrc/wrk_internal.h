@@ -179,6 +179,8 @@ struct MatJob {
 uint32_t matvec_num_wg(const MatJob* jobs, int njobs, int num_cu, uint32_t* rows_per_wg);
 // dry_run: classify only (0 = a launch would honour every job's prologue / carry request, -3 = it cannot)
 int matvec(hipStream_t s, const MatJob* jobs, int njobs, int num_cu, bool dry_run = false);
+// as matvec, but jobs of several quantised kinds are split into one launch per kind (F16 jobs ride with the first)
+int matvec_grouped(hipStream_t s, const MatJob* jobs, int njobs, int num_cu, bool dry_run = false);
 // MFMA dequant-GEMM (wrk_gemm.hip); -2 = not applicable (caller uses the matvec kernels)
 int matmul_mfma(hipStream_t s, const MatJob& job, int num_cu);
 // several matrices x the same tokens in ONE launch (-2 if any job is not for the MFMA path)

@@ -1078,4 +1078,30 @@ int matvec(hipStream_t s, const MatJob* jobs, int njobs, int num_cu, bool dry_ru
     }
 }
 
+// Jobs of several quantised kinds (a real Q4_K_M file keeps attn value / ffn value in Q6_K for half of the layers): one
+// launch per kind -- each on that kind's dedicated kernels, F16 jobs riding with the first -- instead of one launch on the
+// all-kinds catch-all kernel, whose register allocation is the maximum over every decoder.
+int matvec_grouped(hipStream_t s, const MatJob* jobs, int njobs, int num_cu, bool dry_run) {
+    if (njobs <= 0 || njobs > MAX_JOBS) return -1;
+    uint32_t kinds[MAX_JOBS];
+    int nk = 0;
+    for (int j = 0; j < njobs; ++j) {
+        if (jobs[j].kind == WRK_MAT_F16) continue;
+        bool seen = false;
+        for (int q = 0; q < nk; ++q) seen = seen || kinds[q] == jobs[j].kind;
+        if (!seen) kinds[nk++] = jobs[j].kind;
+    }
+    if (nk <= 1) return matvec(s, jobs, njobs, num_cu, dry_run);
+    for (int q = 0; q < nk; ++q) {
+        MatJob g[MAX_JOBS];
+        int n = 0;
+        for (int j = 0; j < njobs; ++j)
+            if (jobs[j].kind == kinds[q] || (q == 0 && jobs[j].kind == WRK_MAT_F16)) g[n++] = jobs[j];
+        // the job that publishes LN(x) must be in the first group (later launches may already consume it)
+        const int rc = matvec(s, g, n, num_cu, dry_run);
+        if (rc != 0) return rc;
+    }
+    return 0;
+}
+
 }  // namespace wrk

@@ -347,7 +347,7 @@ int32_t wrk_v6_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_
             }
             return 0;
         }
-        return wrk::matvec(q, jobs, n, ctx->num_cu);
+        return wrk::matvec_grouped(q, jobs, n, ctx->num_cu);
     };
 #define LNMIX(P, n) do { if (wrk::ln_mix(q, P, n) != 0) return wrk_fail(ctx, WRK_E_UNSUPPORTED, "ln_mix shape"); } while (0)
     {   // embedding rows (already gathered into s.input) -> LN0 -> x
@@ -369,7 +369,7 @@ int32_t wrk_v6_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_
             wrk::MatJob b[2] = {job6(L.ffn_w_k, vec(s.x), vec(s.ffn_k, F), 0), job6(L.ffn_w_r, vec(s.x), vec(s.ffn_r), 0)};
             b[0].pro = b[1].pro = 1;
             wrk::MatJob c = job6(L.ffn_w_v, vec(s.ffn_k, F), vec(s.x), 0); c.gate = s.ffn_r; c.carry_dst = (float*)s.x;
-            single = wrk::matvec(q, &a, 1, ctx->num_cu, true) == 0 && wrk::matvec(q, b, 2, ctx->num_cu, true) == 0 &&
+            single = wrk::matvec(q, &a, 1, ctx->num_cu, true) == 0 && wrk::matvec_grouped(q, b, 2, ctx->num_cu, true) == 0 &&
                      wrk::matvec(q, &c, 1, ctx->num_cu, true) == 0;
         }
         {   // K1

@@ -434,7 +434,7 @@ int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_
             }
             return 0;
         }
-        return matvec(q, jobs, n, ctx->num_cu);
+        return matvec_grouped(q, jobs, n, ctx->num_cu);
     };
 #define LN(P, n)                                                                             \
     do {                                                                                     \
@@ -467,7 +467,7 @@ int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_
             k5.pro = 1;
             MatJob k6 = job(L.ffn_w_v, vec(s.ffn_k, F), vec(s.x), 0);
             k6.carry_dst = (float*)s.x;     // any non-null pointer: classification only
-            single = matvec(q, k1, li ? 7 : 6, ctx->num_cu, true) == 0 && matvec(q, &k5, 1, ctx->num_cu, true) == 0 &&
+            single = matvec_grouped(q, k1, li ? 7 : 6, ctx->num_cu, true) == 0 && matvec(q, &k5, 1, ctx->num_cu, true) == 0 &&
                      matvec(q, &k6, 1, ctx->num_cu, true) == 0;
         }
         uint32_t batch0 = 0;
