@@ -176,6 +176,41 @@ __device__ __forceinline__ void gemm_body(const GemmParams& P, float (*sh_tot)[N
                 for (int i = 0; i < 4; ++i) total[t][i] = __builtin_fmaf(dd[i], acc[i], total[t][i]);
             }
         }
+    } else if (KIND == WRK_MAT_INT8) {
+        // web-rwkv Int8 (matmul_mat_int8, ops.rs:1072-1146): w = code / 255 * (max - min) + min per 128 elements.  The codes
+        // (0..255, exact in f16) and a fragment of ones go through the matrix core; per 128-block
+        //   total += (max - min) / 255 * sum(code * x) + min * sum(x).   Rows are block aligned (K % 128 == 0, host-checked).
+        const uint32_t nblk = K >> 7;
+        const f16 one = (f16)1.0f;
+        const f16x8 ones = {one, one, one, one, one, one, one, one};
+        for (uint32_t b = wave; b < nblk; b += NW) {
+            f32x4v acc[NT], asum[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { acc[t] = (f32x4v){0.f, 0.f, 0.f, 0.f}; asum[t] = (f32x4v){0.f, 0.f, 0.f, 0.f}; }
+            u32x2 q[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) q[j] = *(const u32x2*)(wrow + (size_t)b * 128 + j * 32 + 8 * g);
+            uint32_t mm[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mm[i] = *(const uint32_t*)(P.w + (size_t)min(m0 + 4 * g + i, P.m - 1) * P.row_bytes + K + (size_t)b * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f16x8 a = mul8(codes8(q[j].x, q[j].y), 32768.0f);       // code * 2^-9, exact
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const f16x8 bfr = loadB(t, b * 128 + j * 32);
+                    acc[t] = mfma16(a, bfr, acc[t]);
+                    asum[t] = mfma16(ones, bfr, asum[t]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float mn = (float)__builtin_bit_cast(f16, (uint16_t)(mm[i] & 0xffffu)), mx = (float)__builtin_bit_cast(f16, (uint16_t)(mm[i] >> 16));
+                const float sc = (mx - mn) * (512.0f / 255.0f);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) total[t][i] += sc * acc[t][i] + mn * asum[t][i];
+            }
+        }
     } else if (KIND == WRK_MAT_Q6_K) {
         for (uint32_t b = wave; b < nb; b += NW) {
             f32x4v acc[NT];
@@ -375,6 +410,7 @@ __global__ void __launch_bounds__(64 * NW) gemm_kernel(const GemmBatch B) {
         case WRK_MAT_Q5_K: gemm_body<WRK_MAT_Q5_K, NT, NW>(P, sh_tot); break;
         case WRK_MAT_Q6_K: gemm_body<WRK_MAT_Q6_K, NT, NW>(P, sh_tot); break;
         case WRK_MAT_Q8_0: gemm_body<WRK_MAT_Q8_0, NT, NW>(P, sh_tot); break;
+        case WRK_MAT_INT8: gemm_body<WRK_MAT_INT8, NT, NW>(P, sh_tot); break;
         default: gemm_body<WRK_MAT_F16, NT, NW>(P, sh_tot); break;
     }
 }
@@ -723,6 +759,7 @@ static bool gemm_ok(const MatJob& j, uint32_t n) {
     if ((j.in.stride[0] & 7u) || (j.in.offset[0] & 7u)) return false;
     switch (j.kind) {
         case WRK_MAT_F16: case WRK_MAT_Q8_0: case WRK_MAT_Q6_K: case WRK_MAT_Q4_K: case WRK_MAT_Q5_K: return true;
+        case WRK_MAT_INT8: return (j.k & 127u) == 0;      // rows aligned to the 128-element blocks
         default: return false;
     }
 }
