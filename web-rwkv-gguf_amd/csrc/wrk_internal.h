@@ -178,7 +178,7 @@ struct MatJob {
 };
 uint32_t matvec_num_wg(const MatJob* jobs, int njobs, int num_cu, uint32_t* rows_per_wg);
 // dry_run: classify only (0 = a launch would honour every job's prologue / carry request, -3 = it cannot)
-int matvec(hipStream_t s, const MatJob* jobs, int njobs, int num_cu, bool dry_run = false);
+int matvec(hipStream_t s, const MatJob* jobs, int njobs, int num_cu, bool dry_run = false, bool no_catchall = false);
 // as matvec, but jobs of several quantised kinds are split into one launch per kind (F16 jobs ride with the first)
 int matvec_grouped(hipStream_t s, const MatJob* jobs, int njobs, int num_cu, bool dry_run = false);
 // MFMA dequant-GEMM (wrk_gemm.hip); -2 = not applicable (caller uses the matvec kernels)

@@ -868,6 +868,21 @@ __global__ void __launch_bounds__(256) matvec_reg_kernel(const MatvecParams P) {
     else matvec_body_reg<KB, (KB != WRK_MAT_F16) && R16, (KB == WRK_MAT_F16 ? 4 * XI : XI), 1>(J, smem);
 }
 
+// Three kinds in one launch: a K4 kind, Q6_K and F16 -- the r, k, v + LoRA stage of a real Q4_K_M / Q5_K_M file, whose
+// attn value is Q6_K in about half of the layers.  (KS == 1 only.)
+template <int KA, bool R16, int XI>
+__global__ void __launch_bounds__(256) matvec_reg3_kernel(const MatvecParams P) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[576 + 2 * 4096];
+    int ji = 0;
+#pragma unroll
+    for (int q = 1; q < MAX_JOBS; ++q)
+        if (q < P.njobs && blockIdx.x >= P.jobs[q].wg_begin) ji = q;
+    const JobDev& J = P.jobs[ji];
+    if (J.kind == (uint32_t)KA) matvec_body_reg<KA, R16, XI, 1>(J, smem);
+    else if (J.kind == WRK_MAT_Q6_K) matvec_body_reg<WRK_MAT_Q6_K, R16, XI, 1>(J, smem);
+    else matvec_body_reg<WRK_MAT_F16, false, 4 * XI, 1>(J, smem);
+}
+
 // One kernel per (inputs-per-pass, kind pair, rounding mode): register allocation is the maximum over
 // the code paths a kernel contains, so a launch only carries the decoders its jobs need (a quantised
 // kind plus F16 for the LoRA matrices of the same launch).  KA == KB for single-kind launches;
@@ -941,7 +956,7 @@ static matvec_fn pick_reg_kernel(int ka, int kb, bool r16) {
 }
 
 // register-input decode kernel: one input vector, dense f16 input rows
-static matvec_fn pick_reg(const MatvecParams& P, int quant, bool has_f16, bool r16) {
+static matvec_fn pick_reg(const MatvecParams& P, int quant, bool has_f16, bool r16, int quant2 = -1) {
     uint32_t xi = 1;
     for (int j = 0; j < P.njobs; ++j) {
         const JobDev& J = P.jobs[j];
@@ -966,6 +981,16 @@ static matvec_fn pick_reg(const MatvecParams& P, int quant, bool has_f16, bool r
         if (xi <= 4) return (matvec_fn)matvec_reg_kernel<WRK_MAT_F16, WRK_MAT_F16, false, 4, 1>;
         return small_wg ? (matvec_fn)matvec_reg_kernel<WRK_MAT_F16, WRK_MAT_F16, false, 2, 4> : nullptr;     // 2048 < K <= 4096 (F16)
     }
+    if (quant2 >= 0) {      // (Q4_K | Q5_K) + Q6_K (+ F16), short rows only
+        const int ka = quant == WRK_MAT_Q6_K ? quant2 : quant;
+        if ((quant != WRK_MAT_Q6_K && quant2 != WRK_MAT_Q6_K) || (ka != WRK_MAT_Q4_K && ka != WRK_MAT_Q5_K) || xi > 2) return nullptr;
+        if (ka == WRK_MAT_Q4_K) {
+            if (xi == 1) return r16 ? (matvec_fn)matvec_reg3_kernel<WRK_MAT_Q4_K, true, 1> : (matvec_fn)matvec_reg3_kernel<WRK_MAT_Q4_K, false, 1>;
+            return r16 ? (matvec_fn)matvec_reg3_kernel<WRK_MAT_Q4_K, true, 2> : (matvec_fn)matvec_reg3_kernel<WRK_MAT_Q4_K, false, 2>;
+        }
+        if (xi == 1) return r16 ? (matvec_fn)matvec_reg3_kernel<WRK_MAT_Q5_K, true, 1> : (matvec_fn)matvec_reg3_kernel<WRK_MAT_Q5_K, false, 1>;
+        return r16 ? (matvec_fn)matvec_reg3_kernel<WRK_MAT_Q5_K, true, 2> : (matvec_fn)matvec_reg3_kernel<WRK_MAT_Q5_K, false, 2>;
+    }
     const int kb = has_f16 ? WRK_MAT_F16 : quant;
     if (xi == 1) return pick_reg_kernel<1, 1>(quant, kb, r16);
     if (xi == 2) return pick_reg_kernel<2, 1>(quant, kb, r16);
@@ -975,28 +1000,32 @@ static matvec_fn pick_reg(const MatvecParams& P, int quant, bool has_f16, bool r
 }
 
 template <int NB>
-static int launch_matvec(hipStream_t s, const MatvecParams& P, uint32_t total_wg, uint32_t tok_groups, size_t smem, bool dry) {
+static int launch_matvec(hipStream_t s, const MatvecParams& P, uint32_t total_wg, uint32_t tok_groups, size_t smem, bool dry, bool no_catchall) {
     // classify the kinds of this launch
-    int quant = -1, nquant = 0;
+    int quant = -1, quant2 = -1, nquant = 0;
     bool has_f16 = false, r16 = false, mixed_r16 = false;
     for (int j = 0; j < P.njobs; ++j) {
         const int k = (int)P.jobs[j].kind;
         if (k == WRK_MAT_F16) { has_f16 = true; continue; }
         const bool jr = (P.jobs[j].flags & WRK_MATRIX_ROUND_F16) != 0;
         if (nquant == 0) { quant = k; r16 = jr; nquant = 1; }
-        else { if (k != quant) nquant = 2; if (jr != r16) mixed_r16 = true; }
+        else {
+            if (k != quant && k != quant2) { quant2 = quant2 < 0 ? k : quant2; nquant = (k == quant2) ? 2 : 3; }
+            if (jr != r16) mixed_r16 = true;
+        }
     }
     matvec_fn fn = nullptr;
     bool needs_reg = false;     // fused prologue / state carry exist only in the register-input decode kernel
     for (int j = 0; j < P.njobs; ++j) needs_reg = needs_reg || P.jobs[j].pro || P.jobs[j].carry_dst || P.jobs[j].gate;
-    if (NB == 1 && tok_groups == 1 && nquant <= 1 && !mixed_r16) {
-        fn = pick_reg(P, nquant ? quant : -1, has_f16, r16);
+    if (NB == 1 && tok_groups == 1 && nquant <= 2 && !mixed_r16) {
+        fn = pick_reg(P, nquant ? quant : -1, has_f16, r16, nquant == 2 ? quant2 : -1);
         if (fn) {
             if (!dry) hipLaunchKernelGGL(fn, dim3(total_wg, 1), dim3(256), 0, s, P);
             return 0;
         }
     }
     if (needs_reg) return -3;
+    if (no_catchall && (nquant >= 2 || mixed_r16)) return -4;      // caller splits the jobs by kind instead
     if (dry) return 0;
     if (nquant >= 2 || mixed_r16) fn = (matvec_fn)matvec_kernel<NB, -1, -1, false>;
     else if (nquant == 0) fn = pick_kernel<NB>(WRK_MAT_F16, WRK_MAT_F16, false);
@@ -1038,7 +1067,7 @@ uint32_t matvec_num_wg(const MatJob* jobs, int njobs, int num_cu, uint32_t* rows
 }
 
 // All jobs of one call must have the same number of input vectors (T*B); they run in ONE launch.
-int matvec(hipStream_t s, const MatJob* jobs, int njobs, int num_cu, bool dry_run) {
+int matvec(hipStream_t s, const MatJob* jobs, int njobs, int num_cu, bool dry_run, bool no_catchall) {
     if (njobs <= 0 || njobs > MAX_JOBS) return -1;
     MatvecParams P;
     P.njobs = njobs;
@@ -1071,10 +1100,10 @@ int matvec(hipStream_t s, const MatJob* jobs, int njobs, int num_cu, bool dry_ru
     if (smem < 256) smem = 256;
     const uint32_t groups = (ntok + nb - 1) / nb;
     switch (nb) {
-        case 8: return launch_matvec<8>(s, P, wg, groups, smem, dry_run);
-        case 4: return launch_matvec<4>(s, P, wg, groups, smem, dry_run);
-        case 2: return launch_matvec<2>(s, P, wg, groups, smem, dry_run);
-        default: return launch_matvec<1>(s, P, wg, groups, smem, dry_run);
+        case 8: return launch_matvec<8>(s, P, wg, groups, smem, dry_run, no_catchall);
+        case 4: return launch_matvec<4>(s, P, wg, groups, smem, dry_run, no_catchall);
+        case 2: return launch_matvec<2>(s, P, wg, groups, smem, dry_run, no_catchall);
+        default: return launch_matvec<1>(s, P, wg, groups, smem, dry_run, no_catchall);
     }
 }
 
@@ -1092,6 +1121,10 @@ int matvec_grouped(hipStream_t s, const MatJob* jobs, int njobs, int num_cu, boo
         if (!seen) kinds[nk++] = jobs[j].kind;
     }
     if (nk <= 1) return matvec(s, jobs, njobs, num_cu, dry_run);
+    {   // a K4 kind + Q6_K (+ F16) has its own three-kind register kernel: one launch
+        const int rc = matvec(s, jobs, njobs, num_cu, dry_run, true);
+        if (rc == 0) return 0;
+    }
     for (int q = 0; q < nk; ++q) {
         MatJob g[MAX_JOBS];
         int n = 0;
