@@ -333,8 +333,10 @@ __device__ __forceinline__ void decode_raw(const Raw& r, uint32_t c, Group& lo, 
         const float sc_lo = (float)(int8_t)(r.b.x & 0xffu), sc_hi = (float)(int8_t)((r.b.x >> 8) & 0xffu);
         const float d = f16bits_to_f32(r.b.x >> 16);
         const uint32_t s_lo = part * 2, s_hi = s_lo + 4;
-#define Q6LO(W, H) (((W) & 0x0f0f0f0fu) | ((((H) >> s_lo) & 0x03030303u) << 4))
-#define Q6HI(W, H) ((((W) >> 4) & 0x0f0f0f0fu) | ((((H) >> s_hi) & 0x03030303u) << 4))
+        // bits s, s+1 of every byte of H -> bits 4, 5 of the same byte with one rotate by (s - 4) mod 32 and one mask
+        const uint32_t r_lo = (s_lo + 28u) & 31u, r_hi = (s_hi + 28u) & 31u;
+#define Q6LO(W, H) (((W) & 0x0f0f0f0fu) | (__builtin_amdgcn_alignbit((H), (H), r_lo) & 0x30303030u))
+#define Q6HI(W, H) ((((W) >> 4) & 0x0f0f0f0fu) | (__builtin_amdgcn_alignbit((H), (H), r_hi) & 0x30303030u))
         bytes_to_h2(Q6LO(w.x, qh.x), lo.q[0], lo.q[1]);
         bytes_to_h2(Q6LO(w.y, qh.y), lo.q[2], lo.q[3]);
         bytes_to_h2(Q6LO(w.z, qh.z), lo.q[4], lo.q[5]);
