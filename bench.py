@@ -301,7 +301,7 @@ def main():
             "config": {"workload": (f"RWKV-6 World {args.model[3:]} Q5_K_M (Q5_K matrices, Q6_K head, F16 LoRA) batch={B} greedy decode, "
                                     if args.model in CONFIGS_V6 else
                                     f"RWKV-7 World {args.model} Q4_K_M (Q4_K matrices, Q6_K head, F16 LoRA) batch={B} greedy decode, ") +
-                                   f"{'fused kernels' if args.mode == 1 and args.model not in CONFIGS_V6 else 'one kernel per reference op'} under hipGraph",
+                                   f"{'fused kernels' if args.mode == 1 else 'one kernel per reference op'} under hipGraph",
                        "streams_per_gpu": B, "parallelism": f"replicas x{world}" if world > 1 else "single"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.model, B, args.mode),
