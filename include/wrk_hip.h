@@ -253,6 +253,10 @@ int32_t wrk_v7_state_destroy(wrk_v7_state* state);
 /* State::load / State::back (v7.rs:152-170, 210-217): host f32 [D, S+2, L] for one batch */
 int32_t wrk_v7_state_load(wrk_ctx* ctx, wrk_v7_state* state, uint32_t batch, const float* src);
 int32_t wrk_v7_state_back(wrk_ctx* ctx, const wrk_v7_state* state, uint32_t batch, float* dst);
+/* State::read / State::write (v7.rs:229-262): device-resident snapshot of one batch, f32 [D, S+2, L] in `buf`
+ * (stream-ordered device-to-device copies, no host round trip: multi-session serving keeps snapshots in HBM) */
+int32_t wrk_v7_state_read(wrk_ctx* ctx, const wrk_v7_state* state, uint32_t batch, wrk_buf* buf);
+int32_t wrk_v7_state_write(wrk_ctx* ctx, wrk_v7_state* state, uint32_t batch, const wrk_buf* buf);
 
 /* One RnnJob (load + submit + back, v7.rs:434-492) for a chunk of `num_token` stacked tokens.
  *   tokens     u32 [num_token] ids (device gather from emb_f16), or NULL with

@@ -140,6 +140,28 @@ def test_chunk_split_invariance_and_state_carry(ctx):
     rt.close()
 
 
+def test_device_resident_state_snapshots(ctx):
+    """State::read / State::write (v7.rs:229-262): snapshot a sequence's state in HBM, move it to another batch slot, and
+    continue there -- the continuation equals the original sequence's, bit for bit (same kernels, same data)."""
+    rt, _ = build(ctx, "tiny", wrk.WEIGHTS_INLINE, 3)
+    V = rt.info.num_vocab
+    p = synth.tokens(21, "snap", 40, V)
+    rt.infer(wrk.RnnInput([p, [], []], 64))
+    snap = rt.state_read(0)
+    assert np.array_equal(snap.read(np.float32, rt.state_back(0).size).reshape(rt.state_back(0).shape), rt.state_back(0))
+    rt.state_write(snap, 2)
+    assert np.array_equal(rt.state_back(2), rt.state_back(0))
+    nxt = synth.tokens(22, "cont", 8, V)
+    a = rt.infer(wrk.RnnInput([nxt, [], []], 64))[0]
+    b = rt.infer(wrk.RnnInput([[], [], nxt], 64))[2]
+    assert np.array_equal(a, b)
+    with pytest.raises(wrk.WrkError):
+        rt.state_write(wrk.Buffer(ctx, 64), 1)                # snapshot too small
+    with pytest.raises(wrk.WrkError):
+        rt.state_write(snap, 7)                               # batch out of range
+    rt.close()
+
+
 def test_batched_decode_matches_single_streams(ctx):
     """Independent sequences stacked in one dispatch give the same tokens as running them alone."""
     rt4, _ = build(ctx, "tiny", wrk.WEIGHTS_INLINE, 4)

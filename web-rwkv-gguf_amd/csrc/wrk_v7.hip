@@ -333,6 +333,24 @@ int32_t wrk_v7_state_back(wrk_ctx* ctx, const wrk_v7_state* st, uint32_t batch, 
     return WRK_OK;
 }
 
+static int32_t state_d2d(wrk_ctx* ctx, const wrk_v7_state* st, uint32_t batch, const wrk_buf* buf, bool to_state) {
+    if (!ctx || !st || !buf) return WRK_E_ARG;
+    LOCK(ctx);
+    WRK_ARG(ctx, batch < st->num_batch, "batch %u out of range", batch);
+    const size_t per = (size_t)(st->head_size + 2) * st->num_emb;
+    WRK_ARG(ctx, buf->bytes >= per * st->num_layer * 4, "snapshot buffer holds %zu bytes, a state needs %zu", buf->bytes, per * st->num_layer * 4);
+    WRK_HIP(ctx, hipSetDevice(ctx->device));
+    for (uint32_t l = 0; l < st->num_layer; ++l) {
+        float* slot = st->layer_ptr(l) + batch * per;
+        float* snap = (float*)buf->ptr + l * per;
+        WRK_HIP(ctx, hipMemcpyAsync(to_state ? slot : snap, to_state ? snap : slot, per * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    return WRK_OK;
+}
+
+int32_t wrk_v7_state_read(wrk_ctx* ctx, const wrk_v7_state* st, uint32_t batch, wrk_buf* buf) { return state_d2d(ctx, st, batch, buf, false); }
+int32_t wrk_v7_state_write(wrk_ctx* ctx, wrk_v7_state* st, uint32_t batch, const wrk_buf* buf) { return state_d2d(ctx, st, batch, buf, true); }
+
 int32_t wrk_v7_infer(wrk_ctx* ctx, wrk_v7_model* m, wrk_v7_state* st, const uint32_t* tokens, const uint16_t* emb_rows,
                      const uint32_t* cursors, uint32_t T, const uint32_t* headers, uint32_t NH, float* logits, uint32_t* argmax,
                      uint32_t mode) {

@@ -119,6 +119,8 @@ HIP_SYMBOLS = {
     "wrk_v7_state_create": (C.c_int32, [_P, _P, C.c_uint32, C.POINTER(_P)]),
     "wrk_v7_state_destroy": (C.c_int32, [_P]),
     "wrk_v7_state_load": (C.c_int32, [_P, _P, C.c_uint32, _f32p]),
+    "wrk_v7_state_read": (C.c_int32, [_P, _P, C.c_uint32, _P]),
+    "wrk_v7_state_write": (C.c_int32, [_P, _P, C.c_uint32, _P]),
     "wrk_v7_state_back": (C.c_int32, [_P, _P, C.c_uint32, _f32p]),
     "wrk_v7_infer": (C.c_int32, [_P, _P, _P, _u32p, C.POINTER(C.c_uint16), _u32p, C.c_uint32, _u32p, C.c_uint32, _f32p, _u32p, C.c_uint32]),
     "wrk_v7_generate_greedy": (C.c_int32, [_P, _P, _P, _u32p, C.c_uint32, C.c_uint32, _u32p, _f32p, _f32p, C.c_uint32]),
@@ -643,6 +645,17 @@ class Runtime:
         out = np.empty((L, S + 2, D), np.float32)
         self.ctx.check(hip.wrk_v7_state_back(self.ctx.h, self.state, batch, _ptr(out, _f32p)))
         return out
+
+    def state_read(self, batch: int) -> "Buffer":
+        """`State::read(batch)` (v7.rs:246-262): a device-resident snapshot [L, S+2, D] f32 (no host round trip)."""
+        L, D, S = self.info.num_layer, self.info.num_emb, self.info.num_emb // self.info.num_head
+        buf = Buffer(self.ctx, L * (S + 2) * D * 4)
+        self.ctx.check(hip.wrk_v7_state_read(self.ctx.h, self.state, batch, buf.h))
+        return buf
+
+    def state_write(self, snapshot: "Buffer", batch: int):
+        """`State::write(tensor, batch)` (v7.rs:229-244)."""
+        self.ctx.check(hip.wrk_v7_state_write(self.ctx.h, self.state, batch, snapshot.h))
 
     def state_load(self, tensor: np.ndarray, batch: int):
         a = np.ascontiguousarray(tensor, dtype=np.float32)
