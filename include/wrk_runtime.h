@@ -57,6 +57,11 @@ typedef struct wrk_model_info {         /* ModelInfo (model.rs:30-63) + v7::Cust
 /* Loader::info */
 int32_t wrk_gguf_info(const wrk_gguf* g, wrk_model_info* out);
 
+/* read_state (v7.rs:1229-1262, v6.rs:1176-1208): the pre-trained initial state of a state-tuned model file,
+ * `blocks.N.att.time_state` [H, S, S] placed in rows 1..S of a zeroed f32 [D, S+2, L] state (count = L*(S+2)*D);
+ * feed it to wrk_v7_state_load.  WRK_E_ARG when the file has no time_state tensors. */
+int32_t wrk_gguf_read_state(const wrk_gguf* g, float* out, size_t capacity, size_t* count);
+
 /* ------------------------------------------------------------ RnnInput / RnnIter */
 enum { WRK_RNN_NONE = -1, WRK_RNN_LAST = 0, WRK_RNN_FULL = 1 };
 

@@ -392,3 +392,18 @@ class V7Runtime:
         hx = rnd(layer_norm(hx, m.ln_out[0], m.ln_out[1], LN_EPS))
         logits = np.matmul(hx, m.head.T.astype(np.float32)).astype(np.float32)   # head_o is f32
         return logits
+
+
+def read_state(reader: GgufReader, info=None) -> np.ndarray:
+    """read_state (v7.rs:1229-1262, same in v6.rs:1176-1208): the pre-trained initial state of a state-tuned model.
+    `blocks.N.att.time_state` is stored [H, S, S]; after the reference's transpose + blit, state row 1 + j of channel
+    h*S + c holds time_state[h][j][c]; rows 0 and S+1 (the token-shift rows) stay zero.  -> [L, S+2, D] f32."""
+    info = info or loader_info(reader)
+    S, H, D = info.head_size, info.num_head, info.num_emb
+    out = np.zeros((info.num_layer, S + 2, D), np.float32)
+    for layer in range(info.num_layer):
+        _, shape, vals = reader.tensor(f"blocks.{layer}.att.time_state")
+        ts = r16(vals).reshape(H, S, S)                      # load_matrix_f16: f16 values
+        out[layer, 1:S + 1, :] = ts.transpose(1, 0, 2).reshape(S, D)      # [j][h][c] -> row j, channel h*S + c
+    return out
+

@@ -143,3 +143,32 @@ def test_host_load_time_dequant_kinds(kind):
         got = r.tensor_f16(n)
         _, _, want = oref.tensor(n)
         assert np.array_equal(got.view(np.uint16), want.astype(np.float16).view(np.uint16)), (kind, n)
+
+
+def test_read_state_matches_oracle():
+    """read_state (v7.rs:1229-1262): a state-tuned file's `blocks.N.att.time_state` [H, S, S] lands in rows 1..S of the
+    state, channel h*S + c of row 1 + j = time_state[h][j][c]; the C++ reader and the oracle agree bit for bit."""
+    from oracle.gguf import write_gguf
+    from oracle.quantize import QUANTIZE
+    cfg = synth.CONFIGS["tiny"]
+    H, S, D, L = cfg.num_emb // cfg.head_size, cfg.head_size, cfg.num_emb, cfg.num_layer
+    base = ogguf.GgufReader(synth.make_v7_gguf(cfg, 5))
+    tensors = []
+    for g in base.tensors.values():
+        tensors.append((g.name, list(g.dimensions), g.type_name, np.frombuffer(base.get_tensor_data(g), np.uint8)))
+    rng = np.random.default_rng(3)
+    ts = [(rng.standard_normal((H, S, S)) * 0.1).astype(np.float32) for _ in range(L)]
+    for l in range(L):
+        tensors.append((f"blk.{l}.attn_time_state", [S, S, H], "F16", QUANTIZE["F16"](ts[l])))
+    meta = [("general.architecture", "str", "rwkv7"), ("general.alignment", "u32", 32), ("rwkv7.block_count", "u32", L),
+            ("rwkv7.embedding_length", "u32", D), ("rwkv7.wkv.head_size", "u32", S)]
+    data = write_gguf(meta, tensors)
+    want = orwkv7.read_state(ogguf.GgufReader(data))
+    got = wrk.GgufReader(data).read_state()
+    assert got.shape == want.shape == (L, S + 2, D)
+    assert np.array_equal(got, want)
+    assert np.all(got[:, 0] == 0) and np.all(got[:, S + 1] == 0)
+    l, h, j, c = 1, 2, 5, 7
+    assert got[l, 1 + j, h * S + c] == np.float32(np.float16(ts[l][h, j, c]))
+    with pytest.raises(wrk.WrkError):
+        wrk.GgufReader(synth.make_v7_gguf(cfg, 5)).read_state()      # no time_state tensors in a plain model

@@ -855,6 +855,32 @@ int32_t wrk_rnn_redirect(const uint32_t* lens, const int32_t* options, uint32_t 
     return WRK_OK;
 }
 
+// ---------------------------------------------------------------- read_state (v7.rs:1229-1262)
+int32_t wrk_gguf_read_state(const wrk_gguf* g, float* out, size_t capacity, size_t* count) {
+    if (!g || !count) return fail(WRK_E_ARG, "null argument");
+    wrk_model_info I{};
+    int32_t rc = loader_info(*g, I);
+    if (rc != WRK_OK) return rc;
+    const uint32_t D = I.num_emb, H = I.num_head, S = D / H, L = I.num_layer;
+    const size_t per = (size_t)(S + 2) * D;
+    *count = per * L;
+    if (!out) return WRK_OK;
+    if (capacity < *count) return fail(WRK_E_ARG, "state needs %zu floats, capacity %zu", *count, capacity);
+    std::fill(out, out + *count, 0.0f);
+    for (uint32_t l = 0; l < L; ++l) {
+        const std::string name = "blocks." + std::to_string(l) + ".att.time_state";
+        std::vector<uint16_t> h;
+        rc = g->tensor_f16(name, h);
+        if (rc != WRK_OK) return rc;
+        if (h.size() != (size_t)H * S * S) return fail(WRK_E_ARG, "%s: %zu elements, expected %u x %u x %u", name.c_str(), h.size(), H, S, S);
+        // file order [h][j][c]; after transpose + blit: row 1 + j, channel h*S + c
+        for (uint32_t hh = 0; hh < H; ++hh)
+            for (uint32_t j = 0; j < S; ++j)
+                for (uint32_t c = 0; c < S; ++c) out[l * per + (size_t)(1 + j) * D + hh * S + c] = h2f(h[((size_t)hh * S + j) * S + c]);
+    }
+    return WRK_OK;
+}
+
 // ---------------------------------------------------------------- ModelBuilder::build_v7
 int32_t wrk_runtime_create(wrk_ctx* ctx, const wrk_gguf* g, const wrk_build_options* opt, uint32_t num_batch, wrk_runtime** out) {
     if (!ctx || !g || !out) return fail(WRK_E_ARG, "null argument");

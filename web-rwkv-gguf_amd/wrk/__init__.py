@@ -146,6 +146,7 @@ RT_SYMBOLS = {
     "wrk_gguf_tensor_f16": (C.c_int32, [_P, C.c_char_p, C.POINTER(C.c_uint16), C.c_size_t, C.POINTER(C.c_size_t)]),
     "wrk_gguf_raw": (C.c_int32, [_P, C.c_char_p, _u32p, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "wrk_gguf_meta_u64": (C.c_int32, [_P, C.c_char_p, C.POINTER(C.c_uint64)]),
+    "wrk_gguf_read_state": (C.c_int32, [_P, _f32p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "wrk_gguf_info": (C.c_int32, [_P, C.POINTER(ModelInfo)]),
     "wrk_rnn_input_create": (C.c_int32, [C.c_uint32, C.c_uint32, C.POINTER(_P)]),
     "wrk_rnn_input_destroy": (C.c_int32, [_P]),
@@ -500,6 +501,16 @@ class GgufReader:
         t, p, n = C.c_uint32(), _P(), C.c_size_t()
         _host_check(rt.wrk_gguf_raw(self.h, name.encode(), C.byref(t), C.byref(p), C.byref(n)))
         return t.value, np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n.value,))
+
+    def read_state(self) -> np.ndarray:
+        """`read_state(context, info, reader)` (v7.rs:1229-1262): pre-trained initial state -> [L, S+2, D] f32."""
+        n = C.c_size_t()
+        _host_check(rt.wrk_gguf_read_state(self.h, None, 0, C.byref(n)))
+        mi = self.info()
+        out = np.empty(n.value, np.float32)
+        _host_check(rt.wrk_gguf_read_state(self.h, _ptr(out, _f32p), out.size, C.byref(n)))
+        S = mi.num_emb // mi.num_head
+        return out.reshape(mi.num_layer, S + 2, mi.num_emb)
 
     def info(self) -> ModelInfo:
         """`Loader::info(&reader)`."""
