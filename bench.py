@@ -101,16 +101,28 @@ def _q5k_blocks(rng, n_elem, std):
     return out.reshape(-1)
 
 
-CONFIGS_V6 = {      # SURVEY section 8 cfg 4: L, D, F, V, time_mix rank, time_decay rank
+CONFIGS_V6 = {      # SURVEY section 8 cfg 4 / 5: L, D, F, V, time_mix rank, time_decay rank
     "v6-tiny": (2, 256, 896, 512, 32, 64),
     "v6-7B": (32, 4096, 14336, 65536, 64, 128),
+    "v6-14B": (61, 4096, 14336, 65536, 64, 128),        # cfg 5: Q8_0 file + per-layer Int8 / NF4 map (--quant)
 }
+
+
+def _q8_0_blocks(rng, n_elem, std):
+    nb = n_elem // 32
+    out = np.empty((nb, 34), np.uint8)
+    out[:, 0:2] = _f16b([np.float16(std / 73.9)])            # int8 uniform in [-128, 127]: std 73.9
+    out[:, 2:34] = rng.integers(0, 256, (nb, 32), dtype=np.uint8)
+    return out.reshape(-1)
 
 
 def make_model_gguf_v6(name, seed=42):
     """RWKV-6 "World" architecture, Q5_K_M-style: Q5_K matrices, Q6_K head, F16 embedding, F32 LoRA / vectors
-    (names: gguf.rs:1198-1251)."""
+    (names: gguf.rs:1198-1251); the 14B config is a Q8_0 file (cfg 5)."""
     L, D, F, V, R, W = CONFIGS_V6[name]
+    q8 = name == "v6-14B"
+    mat_id = 8 if q8 else 13
+    mat_blocks = _q8_0_blocks if q8 else _q5k_blocks
     rng = np.random.default_rng(seed)
     tensors = []
 
@@ -137,11 +149,11 @@ def make_model_gguf_v6(name, seed=42):
         f32(p + "attn_time_decay_w1", [D, W], nrm(W * D, 1.0 / np.sqrt(D)))
         f32(p + "attn_time_decay_w2", [W, D], nrm(D * W, 0.5 / np.sqrt(W)))
         for nm in ("k", "v", "r", "g", "output"):
-            tensors.append((p + f"attn_{nm}.weight", [D, D], 13, _q5k_blocks(rng, D * D, (0.5 if nm == "k" else 1.0) / np.sqrt(D))))
+            tensors.append((p + f"attn_{nm}.weight", [D, D], mat_id, mat_blocks(rng, D * D, (0.5 if nm == "k" else (0.1 if nm == "output" else 1.0)) / np.sqrt(D))))
         f32(p + "ffn_time_mix_k", [D], rng.random(D, dtype=np.float32)); f32(p + "ffn_time_mix_r", [D], rng.random(D, dtype=np.float32))
-        tensors.append((p + "ffn_k.weight", [D, F], 13, _q5k_blocks(rng, F * D, 1.0 / np.sqrt(D))))
-        tensors.append((p + "ffn_v.weight", [F, D], 13, _q5k_blocks(rng, D * F, 0.5 / np.sqrt(F))))
-        tensors.append((p + "ffn_r.weight", [D, D], 13, _q5k_blocks(rng, D * D, 1.0 / np.sqrt(D))))
+        tensors.append((p + "ffn_k.weight", [D, F], mat_id, mat_blocks(rng, F * D, 1.0 / np.sqrt(D))))
+        tensors.append((p + "ffn_v.weight", [F, D], mat_id, mat_blocks(rng, D * F, 0.05 / np.sqrt(F))))
+        tensors.append((p + "ffn_r.weight", [D, D], mat_id, mat_blocks(rng, D * D, 1.0 / np.sqrt(D))))
     meta = [("general.architecture", 8, "rwkv6"), ("general.alignment", 4, 32), ("rwkv6.wkv.head_size", 4, 64),
             ("rwkv6.block_count", 4, L), ("rwkv6.embedding_length", 4, D), ("rwkv6.feed_forward_length", 4, F)]
     return _write_gguf(tensors, meta)
@@ -246,6 +258,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="independent streams per GPU")
     ap.add_argument("--mode", type=int, default=1, help="1 = fused decode kernels, 0 = one kernel per reference op")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--quant", default="", help="ModelBuilder::quant map, e.g. int8:0-29,nf4:30-60 (layers inclusive)")
     ap.add_argument("--mixed", action="store_true", help="llama.cpp Q4_K_M tensor mix: Q6_K for attn value / ffn value in about half of the layers")
     args = ap.parse_args()
 
@@ -266,7 +279,13 @@ def main():
     gg = make_model_gguf(args.model, seed=42 + rank, mixed=args.mixed) if args.model not in CONFIGS_V6 else make_model_gguf(args.model, seed=42 + rank)
     ctx = wrk.Context(local_rank)
     reader = wrk.GgufReader(gg)
-    runtime = wrk.Runtime(ctx, reader, num_batch=args.batch, weights=wrk.WEIGHTS_INLINE)
+    quant = {}
+    for part in filter(None, args.quant.split(",")):
+        kind, rng_ = part.split(":")
+        lo, hi = (rng_.split("-") + [rng_])[:2]
+        for l in range(int(lo), int(hi) + 1):
+            quant[l] = {"int8": wrk.QUANT_INT8, "nf4": wrk.QUANT_NF4}[kind]
+    runtime = wrk.Runtime(ctx, reader, num_batch=args.batch, weights=wrk.WEIGHTS_INLINE, quant=quant or None)
     load_s = time.time() - t0
     B = args.batch
     first = [(17 + 101 * b) % (runtime.info.num_vocab - 1) for b in range(B)]
@@ -298,7 +317,8 @@ def main():
             "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
-            "config": {"workload": (f"RWKV-6 World {args.model[3:]} Q5_K_M (Q5_K matrices, Q6_K head, F16 LoRA) batch={B} greedy decode, "
+            "config": {"workload": (f"RWKV-6 World {args.model[3:]} {'Q8_0' if args.model == 'v6-14B' else 'Q5_K_M (Q5_K matrices)'}, Q6_K head, F16 LoRA"
+                                    f"{', quant map ' + args.quant if args.quant else ''}, batch={B} greedy decode, "
                                     if args.model in CONFIGS_V6 else
                                     f"RWKV-7 World {args.model} Q4_K_M (Q4_K matrices, Q6_K head, F16 LoRA) batch={B} greedy decode, ") +
                                    f"{'fused kernels' if args.mode == 1 else 'one kernel per reference op'} under hipGraph",
