@@ -169,3 +169,49 @@ def test_gemm_prefill_tile_kernel_model_shape(ctx):
     want = x.astype(np.float64) @ w.astype(np.float64).T
     bound = 4e-6 * (np.abs(x).astype(np.float64) @ np.abs(w).astype(np.float64).T) + 1e-6
     assert np.all(np.abs(got - want) <= bound), np.abs(got - want).max()
+
+
+def _fuzz_cases(n=48, seed=2024):
+    r = np.random.default_rng(seed)
+    kinds = ["Q4_K", "Q5_K", "Q6_K", "Q8_0", "F16", "INT8", "NF4"]
+    step = {"Q4_K": 256, "Q5_K": 256, "Q6_K": 256, "Q8_0": 32, "F16": 8, "INT8": 128, "NF4": 64}
+    out = []
+    for i in range(n):
+        kind = kinds[i % len(kinds)]
+        k = int(step[kind] * r.integers(1, 1 + (12 if step[kind] == 256 else 40)))
+        if kind == "F16":
+            k = max(k, 32) // 32 * 32 if r.random() < 0.5 else k
+        m = int(r.integers(1, 300))
+        if kind == "INT8":
+            m = max(1, m // 8 * 8)                      # K*M % 128 == 0
+        T = int(r.choice([1, 1, 2, 3, 5, 7, 12, 17, 31, 50, 70]))
+        out.append((kind, k, m, T, bool(r.integers(0, 2))))
+    return out
+
+
+@pytest.mark.parametrize("kind,k,m,T,turbo", _fuzz_cases())
+def test_fuzz_shapes_all_kinds(ctx, kind, k, m, T, turbo):
+    """Seeded random shapes over every matrix kind and both dispatch flags: ragged row counts, odd token counts, K from
+    one block to a dozen.  Same bound as the fixed cases (f32 accumulation of exact products)."""
+    from oracle import wrkquant as wq
+    rng = np.random.default_rng(k * 131 + m * 7 + T)
+    w = (rng.standard_normal((m, k)) / np.sqrt(k)).astype(np.float32)
+    if kind == "INT8":
+        codes, mm = wq.quantize_int8(w.astype(np.float16))
+        raw = np.concatenate([codes, mm.reshape(-1).view(np.uint8)])
+        wd = wq.dequantize_int8(codes, mm).reshape(m, k)
+    elif kind == "NF4":
+        packed, am = wq.quantize_nf4(w.astype(np.float16))
+        raw = np.concatenate([packed, am.view(np.uint8)])
+        wd = wq.dequantize_nf4(packed, am).reshape(m, k)
+    else:
+        raw = qz.QUANTIZE[kind](w)
+        wd = dq.dequantize(kind, raw, k * m, round_f16=False).reshape(m, k)
+    mat = wrk.Matrix(ctx, kind, k, m, raw)
+    x = rng.standard_normal((T, k)).astype(np.float16)
+    out = ctx.zeros([m, T, 1], np.float32)
+    mat.matmul_op(ctx.tensor(x, [k, T, 1]), out, turbo=turbo)
+    got = out.back().reshape(T, m)
+    want = x.astype(np.float64) @ wd.astype(np.float64).T
+    bound = 4e-6 * (np.abs(x).astype(np.float64) @ np.abs(wd).astype(np.float64).T) + 1e-6
+    assert np.all(np.abs(got - want) <= bound), (kind, k, m, T, turbo, float(np.abs(got - want).max()))
