@@ -129,11 +129,16 @@ def test_gemm_activation_residual_f16_out_and_vec_agreement(ctx):
     assert np.all(np.abs(ga - gb) <= np.maximum(np.abs(gb), 2.0 ** -14) * 2.0 ** -10 + 1e-6)     # <= 1 f16 ulp apart
 
 
-@pytest.mark.parametrize("kind,k,m", [("Q4_K", 2048, 130), ("Q5_K", 1024, 200), ("Q4_K", 256, 64), ("Q5_K", 2560, 72)])
-@pytest.mark.parametrize("T", [48, 64, 100, 200])
+# every case satisfies the dispatcher's tile rule (>= 96 tiles of 64 rows x 64 tokens, or >= 64 when K <= 2560), so these run on
+# the LDS-tiled kernel; the first four (12..16 tiles) stay on the K-split kernel and pin the two against the same bound
+@pytest.mark.parametrize("kind,k,m,T", [
+    ("Q4_K", 2048, 130, 200), ("Q5_K", 1024, 200, 100), ("Q4_K", 256, 64, 48), ("Q6_K", 2560, 72, 64),
+    ("Q4_K", 2048, 520, 500), ("Q5_K", 1024, 1030, 250), ("Q4_K", 256, 2050, 130), ("Q5_K", 2560, 520, 470),
+    ("Q6_K", 2048, 520, 500), ("Q6_K", 768, 1030, 250), ("Q6_K", 4096, 1100, 400), ("Q6_K", 256, 2050, 130),
+    ("F16", 2048, 520, 500), ("F16", 96, 2050, 130), ("Q4_K", 4096, 1100, 400)])
 def test_gemm_prefill_tile_kernel(ctx, kind, k, m, T):
-    """The LDS-tiled prefill kernel (>= 48 stacked tokens of one dense [K, T, 1] stack, >= 64 rows, Q4_K / Q5_K):
-    ragged row and token tails, fused activation + residual with f16 output."""
+    """The LDS-tiled prefill kernel (>= 48 stacked tokens of one dense [K, T, 1] stack, >= 64 rows, Q4_K / Q5_K / Q6_K / F16):
+    ragged row and token tails, fused activation with f16 output."""
     raw = make(kind, k, m, k + m + T)
     mat = wrk.Matrix(ctx, kind, k, m, raw)
     w = dq.dequantize(kind, raw, k * m, round_f16=False).reshape(m, k)

@@ -25,11 +25,12 @@ def main():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--repeat", type=int, default=3)
     ap.add_argument("--mode", type=int, default=1)
+    ap.add_argument("--mixed", action="store_true", help="llama.cpp Q4_K_M type mix (Q6_K for half the value matrices and the head)")
     a = ap.parse_args()
     import wrk
     L, D, F, V, lw, la, lv, lg = bench.CONFIGS[a.model]
     ctx = wrk.Context(0)
-    rt = wrk.Runtime(ctx, wrk.GgufReader(bench.make_model_gguf(a.model, seed=42)), num_batch=a.batch, weights=wrk.WEIGHTS_INLINE)
+    rt = wrk.Runtime(ctx, wrk.GgufReader(bench.make_model_gguf(a.model, seed=42, mixed=a.mixed)), num_batch=a.batch, weights=wrk.WEIGHTS_INLINE)
     flop_tok = 2.0 * (12.0 * D * D * L + L * 2.0 * D * (lw + la + lg) + (L - 1) * 2.0 * D * lv)
     best = None
     for rep in range(a.repeat + 1):
@@ -46,7 +47,7 @@ def main():
         if rep and (best is None or dt < best):
             best = dt
     total = a.prompt * a.batch
-    print(json.dumps({"workload": f"RWKV-7 {a.model} Q4_K_M prefill, {a.batch} x {a.prompt} tokens, chunk {a.chunk}", "chunks": n,
+    print(json.dumps({"workload": f"RWKV-7 {a.model} {'Q4_K_M mix' if a.mixed else 'Q4_K'} prefill, {a.batch} x {a.prompt} tokens, chunk {a.chunk}", "chunks": n,
                       "tokens_per_s": round(total / best, 1), "ms": round(best * 1e3, 3),
                       "matrix_TFLOPs": round(total * flop_tok / best / 1e12, 2), "mfma_peak_TFLOPs_f16_dense": 2500.0}))
 

@@ -612,6 +612,112 @@ __device__ __forceinline__ void gemm_tile_body_f16(const GemmParams& P, f16* __r
     }
 }
 
+// Q6_K on the same tiling (the real llama.cpp Q4_K_M mix keeps half the value matrices and the head in Q6_K; on the
+// K-split kernel they made the mixed 32 x 128 prefill 23 % slower than pure Q4_K).  Row layout [ql 128 nb][qh 64 nb]
+// [int8 scales 16 nb][d f16 nb]; codes - 32 and the scale split sc = 2 s1 + s0 stay exact in f16 as in gemm_body.
+__device__ __forceinline__ void gemm_tile_body_q6k(const GemmParams& P, f16* __restrict__ lds) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t r = lane & 15, g = lane >> 4;
+    const uint32_t m0 = (blockIdx.x - P.wg_begin) * TILE_ROWS + wave * 16;
+    const uint32_t n0 = blockIdx.y * TILE_TOK;
+    const uint32_t K = P.k, nb = K >> 8;
+    const uint8_t* wrow = P.w + (size_t)min(m0 + r, P.m - 1) * P.row_bytes;
+    const uint8_t* drow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) drow[i] = P.w + (size_t)min(m0 + 4 * g + i, P.m - 1) * P.row_bytes + (size_t)nb * 208;
+    const size_t xs0 = P.in.stride[0];
+    const f16* xbase = (const f16*)P.in.p + dt_index(P.in, 0, 0, 0) + (size_t)(n0 + (tid >> 5)) * xs0 + (tid & 31u) * 8;
+    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    f16x8 stage[TILE_STAGE];
+    auto fetch_x = [&](uint32_t b) {
+#pragma unroll
+        for (int q = 0; q < TILE_STAGE; ++q)
+            stage[q] = (n0 + (tid >> 5) + 8 * q < P.n && b * 256 + (tid & 31u) * 8 < K) ? *(const f16x8*)(xbase + (size_t)8 * q * xs0 + (size_t)b * 256) : zero8;
+    };
+    auto store_x = [&](uint32_t buf) {
+        f16* base = lds + (size_t)buf * TILE_TOK * TILE_LDS_ROW;
+#pragma unroll
+        for (int q = 0; q < TILE_STAGE; ++q) *(f16x8*)(base + ((tid >> 5) + 8 * q) * TILE_LDS_ROW + (tid & 31u) * 8) = stage[q];
+    };
+    struct WBlk { u32x2 ql[4]; u32x2 qh[2]; u32x4 sc; uint16_t d[4]; };
+    auto load_w = [&](WBlk& R, uint32_t b) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) R.ql[j] = *(const u32x2*)(wrow + (size_t)b * 128 + j * 32 + 8 * g);       // j = 2 n128 + (kq & 1)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) R.qh[h] = *(const u32x2*)(wrow + (size_t)nb * 128 + (size_t)b * 64 + h * 32 + 8 * g);
+        R.sc = *(const u32x4*)(wrow + (size_t)nb * 192 + (size_t)b * 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) R.d[i] = *(const uint16_t*)(drow[i] + (size_t)b * 2);
+    };
+    f32x4v total[TILE_TT];
+#pragma unroll
+    for (int t = 0; t < TILE_TT; ++t) total[t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+    WBlk W0, W1;
+    load_w(W0, 0);
+    fetch_x(0);
+    store_x(0);
+    __syncthreads();
+    const uint32_t gsh = 8 * (g >> 1);       // scale byte of this lane's 16-element half of a 32-group
+    auto step = [&](uint32_t b, uint32_t buf, const WBlk& R, WBlk& Rn) {
+        const bool more = b + 1 < nb;
+        if (more) { load_w(Rn, b + 1); fetch_x(b + 1); }
+        const f16* xt = lds + (size_t)buf * TILE_TOK * TILE_LDS_ROW + r * TILE_LDS_ROW + 8 * g;
+        f32x4v acc[TILE_TT];
+#pragma unroll
+        for (int t = 0; t < TILE_TT; ++t) acc[t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int n128 = 0; n128 < 2; ++n128) {
+            const u32x2 qh = R.qh[n128];
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq) {      // element group 128 n128 + 32 kq + (0..31); scale index 8 n128 + 2 kq + (g >> 1)
+                const u32x2 ql = R.ql[2 * n128 + (kq & 1)];
+                const uint32_t sh = 2 * kq;
+                uint32_t c0, c1;
+                if (kq < 2) { c0 = (ql.x & 0x0f0f0f0fu) | (((qh.x >> sh) & 0x03030303u) << 4); c1 = (ql.y & 0x0f0f0f0fu) | (((qh.y >> sh) & 0x03030303u) << 4); }
+                else { c0 = ((ql.x >> 4) & 0x0f0f0f0fu) | (((qh.x >> sh) & 0x03030303u) << 4); c1 = ((ql.y >> 4) & 0x0f0f0f0fu) | (((qh.y >> sh) & 0x03030303u) << 4); }
+                const f16x8 c = add8(mul8(codes8(c0, c1), 32768.0f), -0.0625f);       // (code - 32) * 2^-9, exact
+                const uint32_t word = R.sc[2 * n128 + (kq >> 1)];
+                const int sc = (int)(int8_t)((word >> (16 * (kq & 1) + gsh)) & 0xffu);
+                const int s1 = sc >> 1, s0 = sc & 1;
+                const f16x8 a1 = mul8(c, (float)(2 * s1)), a0 = mul8(c, (float)s0);
+#pragma unroll
+                for (int t = 0; t < TILE_TT; ++t) {
+                    const f16x8 bfr = *(const f16x8*)(xt + (size_t)t * 16 * TILE_LDS_ROW + n128 * 128 + kq * 32);
+                    acc[t] = mfma16(a1, bfr, acc[t]);
+                    acc[t] = mfma16(a0, bfr, acc[t]);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float d = (float)__builtin_bit_cast(f16, R.d[i]) * 512.0f;
+#pragma unroll
+            for (int t = 0; t < TILE_TT; ++t) total[t][i] = __builtin_fmaf(d, acc[t][i], total[t][i]);
+        }
+        if (more) store_x(buf ^ 1u);
+        __syncthreads();
+    };
+    for (uint32_t b = 0; b < nb; b += 2) {
+        step(b, 0u, W0, W1);
+        if (b + 1 < nb) step(b + 1, 1u, W1, W0);
+    }
+#pragma unroll
+    for (int t = 0; t < TILE_TT; ++t) {
+        const uint32_t tok = n0 + 16 * t + r;
+        if (tok >= P.n) continue;
+        uint32_t tt, bb;
+        tok_tb(P.out, tok, tt, bb);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t mr = m0 + 4 * g + i;
+            if (mr >= P.m) continue;
+            float o = act_apply(P.act, total[t][i] * P.scale);
+            if (P.has_res) { uint32_t rt, rb; tok_tb(P.res, tok, rt, rb); o = dt_round(P.out, o) + dt_load(P.res, dt_index(P.res, mr, rt, rb)); }
+            dt_store(P.out, dt_index(P.out, mr, tt, bb), o);
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) gemm_tile_kernel(const GemmBatch B) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tile_smem[];
     int ji = 0;
@@ -621,6 +727,7 @@ __global__ void __launch_bounds__(256) gemm_tile_kernel(const GemmBatch B) {
     const GemmParams& P = B.jobs[ji];
     if (P.kind == WRK_MAT_Q4_K) gemm_tile_body<WRK_MAT_Q4_K>(P, (f16*)tile_smem);
     else if (P.kind == WRK_MAT_Q5_K) gemm_tile_body<WRK_MAT_Q5_K>(P, (f16*)tile_smem);
+    else if (P.kind == WRK_MAT_Q6_K) gemm_tile_body_q6k(P, (f16*)tile_smem);
     else gemm_tile_body_f16(P, (f16*)tile_smem);
 }
 
@@ -776,7 +883,7 @@ int matmul_mfma_multi(hipStream_t s, const MatJob* jobs, int njobs, int) {
     const uint32_t n = jobs[0].in.shape[1] * jobs[0].in.shape[2];
     for (int j = 0; j < njobs; ++j)
         if (!gemm_ok(jobs[j], n)) return -2;
-    // prefill regime: Q4_K / Q5_K matrices with >= 64 rows go to the LDS-tiled kernel, the rest (LoRA, Q6_K, Q8_0, F16)
+    // prefill regime: Q4_K / Q5_K / Q6_K / F16 matrices with >= 64 rows go to the LDS-tiled kernel, the rest (Q8_0, Int8, short)
     // to the K-split kernel, each group in one launch
     static const bool use_tile = [] { const char* e = getenv("WRK_GEMM_TILE"); return !(e && e[0] == '0'); }();
     // measured (round 1): SLOWER than the K-split kernel -- 12.2 vs 8.9 us for 8192 x 2048 x 16 tokens, batch-16 decode 2.35 vs
@@ -796,7 +903,7 @@ int matmul_mfma_multi(hipStream_t s, const MatJob* jobs, int njobs, int) {
         // the tile kernel walks the whole K in every wave: it needs enough workgroups to fill the chip (a 2048 x 8192
         // matrix x 128 tokens has only 64 tiles and is faster on the K-split kernel: 44 vs 74 us)
         const uint32_t tiles = ((j.m + TILE_ROWS - 1) / TILE_ROWS) * ((n + TILE_TOK - 1) / TILE_TOK);
-        const bool tile = use_tile && n >= 48 && (j.kind == WRK_MAT_Q4_K || j.kind == WRK_MAT_Q5_K || j.kind == WRK_MAT_F16) && j.m >= 64 &&
+        const bool tile = use_tile && n >= 48 && (j.kind == WRK_MAT_Q4_K || j.kind == WRK_MAT_Q5_K || j.kind == WRK_MAT_Q6_K || j.kind == WRK_MAT_F16) && j.m >= 64 &&
                           j.in.shape[2] == 1 && (tiles >= 96 || (j.k <= 2560 && tiles >= 64));     // enough workgroups, or a short serial walk
         if (tile) { fill_job(T.jobs[T.njobs++], j, n, twg); twg += (j.m + TILE_ROWS - 1) / TILE_ROWS; }
         else { fill_job(B.jobs[B.njobs++], j, n, wg); wg += (j.m + 15) / 16; kmax = j.k > kmax ? j.k : kmax; }
