@@ -922,6 +922,8 @@ int matmul_mfma_multi(hipStream_t s, const MatJob* jobs, int njobs, int) {
         // tokens per wave: enough tiles to amortise the decode, few enough to keep >= ~2 waves per SIMD;
         // few row tiles x long rows (decode batches through ffn.value): 8 waves split K so a wave's serial chain is short
         const bool deep = wg < 256 && kmax >= 4096;
+        // (measured, round 1: 16 waves x 2 blocks for K = 8192 is SLOWER, 23 vs 12 us at 2..16 tokens: 128 VGPRs per lane at 1024
+        // threads spill the all-kinds kernel to scratch)
         if (n > 64) gemm_kernel<4, 4><<<dim3(wg, (n + 63) / 64), 256, 0, s>>>(B);
         else if (n > 16) { if (deep) gemm_kernel<2, 8><<<dim3(wg, (n + 31) / 32), 512, 0, s>>>(B); else gemm_kernel<2, 4><<<dim3(wg, (n + 31) / 32), 256, 0, s>>>(B); }
         else { if (deep) gemm_kernel<1, 8><<<dim3(wg, (n + 15) / 16), 512, 0, s>>>(B); else gemm_kernel<1, 4><<<dim3(wg, (n + 15) / 16), 256, 0, s>>>(B); }

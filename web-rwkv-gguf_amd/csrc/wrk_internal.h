@@ -128,6 +128,8 @@ void layer_norm(hipStream_t s, const void* w, const void* b, DTensor x, float ep
 void group_norm(hipStream_t s, const void* w, const void* b, DTensor x, float eps);
 void l2_norm(hipStream_t s, DTensor x, float eps);
 void token_shift(hipStream_t s, const uint32_t* cursors, DTensor mix, DTensor state, DTensor in, DTensor out, int reversed);
+// n <= 6 token_shift ops over the same input / state row in one pass (falls back to n launches for views it cannot vectorise)
+void token_shift_multi(hipStream_t s, const uint32_t* cursors, const DTensor* mix, const DTensor* out, int n, DTensor state, DTensor in, int reversed);
 void transpose(hipStream_t s, DTensor in, DTensor out);
 void time_mix_v6(hipStream_t s, const uint32_t* cursors, DTensor decay, const void* u_f32, DTensor state, DTensor k, DTensor v, DTensor r, DTensor x);
 void channel_mix_v6(hipStream_t s, const uint32_t* cursors, DTensor state, DTensor r, DTensor v, DTensor x);

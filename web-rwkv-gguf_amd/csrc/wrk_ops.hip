@@ -127,6 +127,51 @@ void token_shift(hipStream_t s, const uint32_t* cursors, DTensor mixw, DTensor s
     token_shift_kernel<<<grid, 256, 0, s>>>(cursors, mixw, st, in, out, reversed);
 }
 
+// Several token_shift ops over the SAME input and state row in one pass (the six att shifts of an RWKV-7 layer,
+// v7.rs:760-790): x and its predecessor are read once, every output is the same wgsl_mix expression as above.
+struct ShiftSet { DTensor mixw[6]; DTensor out[6]; int n; };
+__global__ void __launch_bounds__(256) token_shift_multi_v8_kernel(const uint32_t* __restrict__ cursors, ShiftSet S, DTensor st, DTensor in, int reversed) {
+    const uint32_t c = (blockIdx.x * 256 + threadIdx.x) * 8;
+    const uint32_t stack = blockIdx.y;
+    if (c >= in.shape[0]) return;
+    const Cursor cur = unpack_cursor(cursors[stack]);
+    const f16x8 xt = ld8(in, dt_index(in, c, stack, 0));
+    float prev[8];
+    if (stack == cur.token) {
+        const float* sp = (const float*)st.p + dt_index(st, c, 0, cur.batch);
+        const f32x4 p0 = *(const f32x4*)sp, p1 = *(const f32x4*)(sp + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { prev[e] = p0[e]; prev[4 + e] = p1[e]; }
+    } else {
+        const f16x8 pv = ld8(in, dt_index(in, c, stack - 1, 0));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) prev[e] = (float)pv[e];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        if (i >= S.n) break;
+        const f16x8 f = ld8(S.mixw[i], dt_index(S.mixw[i], c, 0, 0));
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (f16)(reversed ? wgsl_mix((float)xt[e], prev[e], (float)f[e]) : wgsl_mix(prev[e], (float)xt[e], (float)f[e]));
+        st8(S.out[i], dt_index(S.out[i], c, stack, 0), o);
+    }
+}
+
+void token_shift_multi(hipStream_t s, const uint32_t* cursors, const DTensor* mixw, const DTensor* out, int n, DTensor st, DTensor in, int reversed) {
+    if (in.shape[1] == 0 || n <= 0) return;
+    bool fast = n <= 6 && vec8_ok(in) && st.dtype == WRK_F32 && (st.offset[0] & 3u) == 0 && (st.stride[0] & 3u) == 0 && (((uintptr_t)st.p) & 15u) == 0;
+    for (int i = 0; i < n && fast; ++i) fast = vec8_ok(mixw[i]) && vec8_ok(out[i]) && mixw[i].shape[1] == 1 && out[i].shape[2] <= 1;
+    if (!fast) {
+        for (int i = 0; i < n; ++i) token_shift(s, cursors, mixw[i], st, in, out[i], reversed);
+        return;
+    }
+    ShiftSet S;
+    S.n = n;
+    for (int i = 0; i < 6; ++i) { S.mixw[i] = mixw[i < n ? i : 0]; S.out[i] = out[i < n ? i : 0]; }
+    token_shift_multi_v8_kernel<<<dim3((in.shape[0] / 8 + 255) / 256, in.shape[1]), 256, 0, s>>>(cursors, S, st, in, reversed);
+}
+
 // ------------------------------------------------------------------ add / mul (binary.wgsl:38-78)
 __global__ void __launch_bounds__(256) binary_kernel(int is_mul, DTensor in, DTensor out, uint32_t ax, uint32_t ay, uint32_t ao) {
     const uint32_t c = blockIdx.x * 256 + threadIdx.x;

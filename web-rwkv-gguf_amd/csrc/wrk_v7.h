@@ -56,7 +56,7 @@ struct wrk_v7_model {
     int32_t ensure_scratch(uint32_t T, uint32_t NH);
     int32_t ensure_history(size_t n);
     void drop_graphs();
-    int32_t enqueue_ops(wrk_v7_state* st, uint32_t T, uint32_t NH, bool identity_headers);
+    int32_t enqueue_ops(wrk_v7_state* st, uint32_t T, uint32_t NH, bool identity_headers, bool merged = false);
     // from_tokens: gather embedding rows of s.tokens on the device; want_argmax: greedy token per header row into
     // s.argmax; advance: also feed it back as the next token (device-resident generation loop)
     int32_t enqueue_fused_decode(wrk_v7_state* st, uint32_t B, uint32_t NH, bool identity_headers, bool from_tokens,

@@ -88,6 +88,18 @@ static int32_t mm(wrk_ctx* ctx, const wrk_matrix* m, DTensor in, DTensor out, ui
     if (rc != 0) return wrk_fail(ctx, WRK_E_ARG, "matmul launch rejected (K=%u M=%u)", m->k, m->m);
     return WRK_OK;
 }
+// several matrices x the same token count in one MFMA launch per kernel family; per-matrix launches when the GEMM declines
+static int32_t mm_group(wrk_ctx* ctx, wrk::MatJob* jobs, int n) {
+    const uint32_t T = jobs[0].in.shape[1] * jobs[0].in.shape[2];
+    if (T >= wrk::gemm_min_tokens() && wrk::matmul_mfma_multi(ctx->stream, jobs, n, ctx->num_cu) == 0) return WRK_OK;
+    for (int i = 0; i < n; ++i) {
+        int rc = -2;
+        if (T >= wrk::gemm_min_tokens()) rc = wrk::matmul_mfma(ctx->stream, jobs[i], ctx->num_cu);
+        if (rc == -2) rc = wrk::matvec(ctx->stream, &jobs[i], 1, ctx->num_cu);
+        if (rc != 0) return wrk_fail(ctx, WRK_E_ARG, "matmul launch rejected (K=%u M=%u)", jobs[i].k, jobs[i].m);
+    }
+    return WRK_OK;
+}
 #define MM(...)                                   \
     do {                                          \
         int32_t _r = mm(ctx, __VA_ARGS__);        \
@@ -95,7 +107,7 @@ static int32_t mm(wrk_ctx* ctx, const wrk_matrix* m, DTensor in, DTensor out, ui
     } while (0)
 
 // ------------------------------------------------------------------ mode 0: the reference op list
-int32_t wrk_v7_model::enqueue_ops(wrk_v7_state* st, uint32_t T, uint32_t NH, bool identity_headers) {
+int32_t wrk_v7_model::enqueue_ops(wrk_v7_state* st, uint32_t T, uint32_t NH, bool identity_headers, bool merged) {
     hipStream_t q = ctx->stream;
     const uint32_t D = d.num_emb, F = d.num_hidden, H = d.num_head, S = D / H, V = d.num_vocab;
     auto vec = [&](void* p, uint32_t c = 0) { return make_dense(p, WRK_F16, c ? c : D, T); };
@@ -126,23 +138,42 @@ int32_t wrk_v7_model::enqueue_ops(wrk_v7_state* st, uint32_t T, uint32_t NH, boo
 
         wrk::blit(q, x, att_x);                                                          // 1
         wrk::layer_norm(q, L.ln1_w->ptr, L.ln1_b->ptr, att_x, LN_EPS);                   // 2
-        wrk::token_shift(q, s.cursors, bvec(L.x_r), st_row0, att_x, rx, 1);               // 3
-        wrk::token_shift(q, s.cursors, bvec(L.x_w), st_row0, att_x, wx, 1);
-        wrk::token_shift(q, s.cursors, bvec(L.x_k), st_row0, att_x, kx, 1);
-        wrk::token_shift(q, s.cursors, bvec(L.x_v), st_row0, att_x, vx, 1);
-        wrk::token_shift(q, s.cursors, bvec(L.x_a), st_row0, att_x, ax, 1);
-        wrk::token_shift(q, s.cursors, bvec(L.x_g), st_row0, att_x, gx, 1);
-        MM(L.w_r, rx, r, WRK_ACT_NONE);                                                  // 4
-        MM(L.w_k, kx, k, WRK_ACT_NONE);
-        MM(L.w_v, vx, v, WRK_ACT_NONE);
-        MM(L.w1, wx, aux_w, WRK_ACT_TANH);                                               // 5
-        MM(L.w2, aux_w, w, WRK_ACT_NONE);
-        wrk::binary(q, 0, bvec(L.w0), w, 0, 0, 0);
-        MM(L.a1, ax, aux_a, WRK_ACT_NONE);                                               // 6
-        MM(L.a2, aux_a, a, WRK_ACT_NONE);
-        wrk::binary(q, 0, bvec(L.a0), a, 0, 0, WRK_ACT_SIGMOID);
-        MM(L.g1, gx, aux_g, WRK_ACT_SIGMOID);                                            // 7
-        MM(L.g2, aux_g, g, WRK_ACT_NONE);
+        if (merged) {
+            // same arithmetic, fewer launches (mode 1, multi-token chunks): the six shifts read LN(x) once; the projections
+            // that are ready together share a launch (r, k, v, LoRA downs | LoRA ups)
+            const DTensor mixes[6] = {bvec(L.x_r), bvec(L.x_w), bvec(L.x_k), bvec(L.x_v), bvec(L.x_a), bvec(L.x_g)};
+            const DTensor outs[6] = {rx, wx, kx, vx, ax, gx};
+            wrk::token_shift_multi(q, s.cursors, mixes, outs, 6, st_row0, att_x, 1);
+            wrk::MatJob ja[7] = {mj(L.w_r, rx, r, WRK_ACT_NONE), mj(L.w_k, kx, k, WRK_ACT_NONE), mj(L.w_v, vx, v, WRK_ACT_NONE),
+                                 mj(L.w1, wx, aux_w, WRK_ACT_TANH), mj(L.a1, ax, aux_a, WRK_ACT_NONE), mj(L.g1, gx, aux_g, WRK_ACT_SIGMOID),
+                                 mj(li ? L.v1 : L.a1, li ? vx : ax, li ? aux_v : aux_a, WRK_ACT_NONE)};
+            int32_t rg = mm_group(ctx, ja, li ? 7 : 6);
+            if (rg != WRK_OK) return rg;
+            wrk::MatJob jb[4] = {mj(L.w2, aux_w, w, WRK_ACT_NONE), mj(L.a2, aux_a, a, WRK_ACT_NONE), mj(L.g2, aux_g, g, WRK_ACT_NONE),
+                                 mj(li ? L.v2 : L.a2, li ? aux_v : aux_a, li ? vv : a, WRK_ACT_NONE)};
+            rg = mm_group(ctx, jb, li ? 4 : 3);
+            if (rg != WRK_OK) return rg;
+            wrk::binary(q, 0, bvec(L.w0), w, 0, 0, 0);
+            wrk::binary(q, 0, bvec(L.a0), a, 0, 0, WRK_ACT_SIGMOID);
+        } else {
+            wrk::token_shift(q, s.cursors, bvec(L.x_r), st_row0, att_x, rx, 1);               // 3
+            wrk::token_shift(q, s.cursors, bvec(L.x_w), st_row0, att_x, wx, 1);
+            wrk::token_shift(q, s.cursors, bvec(L.x_k), st_row0, att_x, kx, 1);
+            wrk::token_shift(q, s.cursors, bvec(L.x_v), st_row0, att_x, vx, 1);
+            wrk::token_shift(q, s.cursors, bvec(L.x_a), st_row0, att_x, ax, 1);
+            wrk::token_shift(q, s.cursors, bvec(L.x_g), st_row0, att_x, gx, 1);
+            MM(L.w_r, rx, r, WRK_ACT_NONE);                                                  // 4
+            MM(L.w_k, kx, k, WRK_ACT_NONE);
+            MM(L.w_v, vx, v, WRK_ACT_NONE);
+            MM(L.w1, wx, aux_w, WRK_ACT_TANH);                                               // 5
+            MM(L.w2, aux_w, w, WRK_ACT_NONE);
+            wrk::binary(q, 0, bvec(L.w0), w, 0, 0, 0);
+            MM(L.a1, ax, aux_a, WRK_ACT_NONE);                                               // 6
+            MM(L.a2, aux_a, a, WRK_ACT_NONE);
+            wrk::binary(q, 0, bvec(L.a0), a, 0, 0, WRK_ACT_SIGMOID);
+            MM(L.g1, gx, aux_g, WRK_ACT_SIGMOID);                                            // 7
+            MM(L.g2, aux_g, g, WRK_ACT_NONE);
+        }
         wrk::blit(q, k, kk);                                                             // 8
         wrk::binary(q, 1, bvec(L.k_k), kk, 0, 0, 0);
         wrk::l2_norm(q, heads(s.kk), L2_EPS);
@@ -150,8 +181,10 @@ int32_t wrk_v7_model::enqueue_ops(wrk_v7_state* st, uint32_t T, uint32_t NH, boo
         if (li == 0) {                                                                   // 10
             wrk::blit(q, v, v0);
         } else {
-            MM(L.v1, vx, aux_v, WRK_ACT_NONE);
-            MM(L.v2, aux_v, vv, WRK_ACT_NONE);
+            if (!merged) {
+                MM(L.v1, vx, aux_v, WRK_ACT_NONE);
+                MM(L.v2, aux_v, vv, WRK_ACT_NONE);
+            }
             wrk::binary(q, 0, bvec(L.v0), vv, 0, 0, WRK_ACT_SIGMOID);
             wrk::lerp(q, v0, v, vv, 1);
         }
@@ -163,8 +196,16 @@ int32_t wrk_v7_model::enqueue_ops(wrk_v7_state* st, uint32_t T, uint32_t NH, boo
         wrk::group_norm(q, L.gn_w->ptr, L.gn_b->ptr, heads(s.att_x), GN_EPS);            // 13
         wrk::time_first_v7(q, L.r_k->ptr, heads(s.r), n4, heads(s.att_x));               // 14
         wrk::binary(q, 1, g, att_x, 0, 0, 0);                                            // 15
-        MM(L.w_o, att_x, o, WRK_ACT_NONE);                                               // 16
-        wrk::binary(q, 0, o, x, 0, 0, 0);
+        if (merged) {       // the add rides the projection's epilogue: x = round(W_o att_x) + x
+            wrk::MatJob jo = mj(L.w_o, att_x, x, WRK_ACT_NONE);
+            jo.has_res = 1;
+            jo.res = x;
+            const int32_t rg = mm_group(ctx, &jo, 1);
+            if (rg != WRK_OK) return rg;
+        } else {
+            MM(L.w_o, att_x, o, WRK_ACT_NONE);                                           // 16
+            wrk::binary(q, 0, o, x, 0, 0, 0);
+        }
         wrk::blit(q, x, ffn_x);                                                          // 17
         wrk::layer_norm(q, L.ln2_w->ptr, L.ln2_b->ptr, ffn_x, LN_EPS);
         wrk::token_shift(q, s.cursors, bvec(L.ffn_x_k), st_ffn, ffn_x, ffn_kx, 1);        // 18
@@ -406,7 +447,7 @@ int32_t wrk_v7_infer(wrk_ctx* ctx, wrk_v7_model* m, wrk_v7_state* st, const uint
         int32_t r;
         if (fused) r = m->enqueue_fused_decode(st, T, NH, identity, tokens != nullptr, NH && argmax, false, cursors[0] & 0xff);
         else {
-            r = m->enqueue_ops(st, T, NH, identity);
+            r = m->enqueue_ops(st, T, NH, identity, mode == 1);
             if (r == WRK_OK && NH && argmax) wrk::argmax_rows(ctx->stream, m->s.head_o, V, V, NH, m->s.argmax);
         }
         return r;
