@@ -223,3 +223,27 @@ def test_empty_and_maximum_chunks(ctx):
     with pytest.raises(wrk.WrkError):
         rt.infer(wrk.RnnInput([synth.tokens(1, "x", 300, V)], 512))     # 300 tokens of one sequence in one chunk
     rt.close()
+
+
+@pytest.mark.parametrize("name,kw", [("tiny", {}), ("small", {"mat_override": {"time_mix_value": "Q6_K", "channel_mix_value": "Q6_K"}})])
+def test_merged_prefill_launches_are_bit_identical_to_the_op_list(ctx, name, kw):
+    """Mode 1 runs a multi-token chunk with fewer launches (six shifts in one pass, projections grouped per stage, the
+    element-wise chains before and after the WKV kernel in one launch each, W_o's add in the GEMM epilogue).  Every
+    intermediate is rounded where the separate ops store it and the reductions are the same, so above 64 stacked
+    tokens (where the GEMM kernel choice cannot differ) logits and state must EQUAL mode 0's, not just be close."""
+    data = synth.make_v7_gguf(synth.CONFIGS[name], 7, **kw)
+    V = synth.CONFIGS[name].num_vocab
+    p0, p1 = synth.tokens(5, "merged-a", 70, V), synth.tokens(5, "merged-b", 26, V)
+    out = []
+    for mode in (0, 1):
+        rt = wrk.Runtime(ctx, wrk.GgufReader(data), num_batch=2, weights=wrk.WEIGHTS_INLINE)
+        inp = wrk.RnnInput([p0, p1], 96, [wrk.RNN_FULL, wrk.RNN_LAST])
+        logits = rt.infer(inp, mode=mode)
+        nxt = rt.infer(wrk.RnnInput([[3] * 40, [5] * 33], 128), mode=mode)      # second chunk on the carried state
+        out.append((logits, nxt, rt.state_back(0), rt.state_back(1)))
+        rt.close()
+    (l0, n0, a0, b0), (l1, n1, a1, b1) = out
+    assert l0[0].shape == (70, V) and l0[1].shape == (1, V)
+    for x, y in zip(l0 + n0, l1 + n1):
+        assert np.array_equal(x, y), float(np.abs(x - y).max())
+    assert np.array_equal(a0, a1) and np.array_equal(b0, b1)

@@ -128,6 +128,11 @@ void layer_norm(hipStream_t s, const void* w, const void* b, DTensor x, float ep
 void group_norm(hipStream_t s, const void* w, const void* b, DTensor x, float eps);
 void l2_norm(hipStream_t s, DTensor x, float eps);
 void token_shift(hipStream_t s, const uint32_t* cursors, DTensor mix, DTensor state, DTensor in, DTensor out, int reversed);
+// merged element-wise stages of an RWKV-7 layer over dense f16 [D, T] rows with 64-wide heads (bit-identical to the op chain)
+void pre_wkv_v7(hipStream_t s, void* w, void* a, void* k, void* v, void* vv, void* v0, void* n, const void* w0, const void* a0, const void* k_k,
+                const void* k_a, const void* v0p, uint32_t D, uint32_t T, bool first_layer, float l2_eps);
+void post_wkv_v7(hipStream_t s, void* x, const void* r, const void* g, const void* n, const void* gn_w, const void* gn_b, const void* r_k,
+                 uint32_t D, uint32_t T, float gn_eps);
 // n <= 6 token_shift ops over the same input / state row in one pass (falls back to n launches for views it cannot vectorise)
 void token_shift_multi(hipStream_t s, const uint32_t* cursors, const DTensor* mix, const DTensor* out, int n, DTensor state, DTensor in, int reversed);
 void transpose(hipStream_t s, DTensor in, DTensor out);

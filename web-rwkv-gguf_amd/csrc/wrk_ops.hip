@@ -475,6 +475,79 @@ void time_mix_v7(hipStream_t s, const uint32_t* cursors, DTensor st, DTensor r, 
         time_mix_v7_kernel<<<grid, 256, 0, s>>>(cursors, st, r, w, n, x);
 }
 
+// ------------------------------------------------------------------ merged element-wise stages of an RWKV-7 layer (mode 1, multi-token)
+// The op list between the projections and the WKV kernel (v7.rs:826-905) is a dozen launches of one f16 row each:
+//   w += w0 | a = sigmoid(a + a0) | kk = l2_norm(k * k_k) per head | k *= 1 + (a - 1) * k_a | v = mix(v, v0, sigmoid(vv + v0p))
+//   (layer 0: v0 = v) | n[0..3] = k, v, a, kk
+// One wave per (head, token) does all of it with every intermediate rounded to f16 exactly where the separate ops
+// store it, and the same wave_sum for the per-head norm, so the results are bit-identical to the op chain.
+// f32 -> f16 of a value that must first exist as an f32: without the barrier the compiler folds `(f16)(h * f)` into
+// v_fma_mixlo_f16 (ONE rounding of the exact product), while the separate ops round the product to f32 and then to f16 --
+// rare last-bit differences (seen as 2e-3 on a logit after 33 tokens).
+__device__ __forceinline__ f16 to_h(float v) { asm volatile("" : "+v"(v)); return (f16)v; }
+struct PreWkvParams {
+    f16 *w, *a, *k, *v, *vv, *v0, *n;         // dense f16 [D, T] rows (n: [S, H, T, 4])
+    const f16 *w0, *a0, *k_k, *k_a, *v0p;
+    uint32_t D, T, first_layer;
+    float l2_eps;
+};
+__global__ void __launch_bounds__(64) pre_wkv_v7_kernel(const PreWkvParams P) {
+    const uint32_t head = blockIdx.x, t = blockIdx.y, c = head * 64 + threadIdx.x;
+    const size_t i = (size_t)t * P.D + c, plane = (size_t)P.T * P.D;
+    const f16 wn = to_h((float)P.w0[c] + (float)P.w[i]);
+    const f16 an = to_h(act_sigmoid((float)P.a0[c] + (float)P.a[i]));
+    const f16 k0 = P.k[i];
+    const f16 kk0 = to_h((float)P.k_k[c] * (float)k0);
+    const float ss = wave_sum((float)kk0 * (float)kk0);
+    const f16 kk1 = to_h((float)kk0 * (1.0f / sqrtf(ss + P.l2_eps)));
+    const f16 kn = to_h((float)k0 * (1.0f + ((float)an - 1.0f) * (float)P.k_a[c]));
+    f16 vn = P.v[i];
+    if (P.first_layer) P.v0[i] = vn;
+    else {
+        const f16 f = to_h(act_sigmoid((float)P.v0p[c] + (float)P.vv[i]));
+        vn = to_h(wgsl_mix((float)vn, (float)P.v0[i], (float)f));
+    }
+    P.w[i] = wn;
+    P.n[i] = kn;
+    P.n[plane + i] = vn;
+    P.n[2 * plane + i] = an;
+    P.n[3 * plane + i] = kk1;
+}
+void pre_wkv_v7(hipStream_t s, void* w, void* a, void* k, void* v, void* vv, void* v0, void* n, const void* w0, const void* a0, const void* k_k,
+                const void* k_a, const void* v0p, uint32_t D, uint32_t T, bool first_layer, float l2_eps) {
+    if (T == 0) return;
+    PreWkvParams P{(f16*)w, (f16*)a, (f16*)k, (f16*)v, (f16*)vv, (f16*)v0, (f16*)n, (const f16*)w0, (const f16*)a0, (const f16*)k_k, (const f16*)k_a,
+                   (const f16*)v0p, D, T, first_layer ? 1u : 0u, l2_eps};
+    pre_wkv_v7_kernel<<<dim3(D / 64, T), 64, 0, s>>>(P);
+}
+
+// group_norm -> time_first -> * g after the WKV kernel (v7.rs:918-946), same contract as above
+struct PostWkvParams {
+    f16* x;                                    // WKV output, [D, T]
+    const f16 *r, *g, *n, *gn_w, *gn_b, *r_k;
+    uint32_t D, T;
+    float gn_eps;
+};
+__global__ void __launch_bounds__(64) post_wkv_v7_kernel(const PostWkvParams P) {
+    const uint32_t head = blockIdx.x, t = blockIdx.y, c = head * 64 + threadIdx.x;
+    const size_t i = (size_t)t * P.D + c, plane = (size_t)P.T * P.D;
+    const float x0 = (float)P.x[i];
+    const float mean = wave_sum(x0) / 64.0f;
+    const float dlt = x0 - mean;
+    const float var = wave_sum(dlt * dlt) / 64.0f + P.gn_eps;
+    const float dev = 1.0f / sqrtf(var);
+    const f16 y = to_h(__builtin_fmaf((x0 - mean) * dev, (float)P.gn_w[c], (float)P.gn_b[c]));
+    const float xx = wave_sum((float)P.r_k[c] * (float)P.n[i] * (float)P.r[i]);
+    const f16 y2 = to_h((float)y + xx * (float)P.n[plane + i]);
+    P.x[i] = to_h((float)P.g[i] * (float)y2);
+}
+void post_wkv_v7(hipStream_t s, void* x, const void* r, const void* g, const void* n, const void* gn_w, const void* gn_b, const void* r_k,
+                 uint32_t D, uint32_t T, float gn_eps) {
+    if (T == 0) return;
+    PostWkvParams P{(f16*)x, (const f16*)r, (const f16*)g, (const f16*)n, (const f16*)gn_w, (const f16*)gn_b, (const f16*)r_k, D, T, gn_eps};
+    post_wkv_v7_kernel<<<dim3(D / 64, T), 64, 0, s>>>(P);
+}
+
 // ------------------------------------------------------------------ time_first_v7 (time_mix_v7.wgsl:223-262)
 // x[i] += (sum_j u[j] * k[j] * r[j]) * v[i] per head; one wave per (head, token)
 __global__ void __launch_bounds__(64) time_first_v7_kernel(const f16* __restrict__ u, DTensor r, DTensor n, DTensor x) {

@@ -121,6 +121,12 @@ int32_t wrk_v7_model::enqueue_ops(wrk_v7_state* st, uint32_t T, uint32_t NH, boo
     DTensor n4 = make_dense(s.n, WRK_F16, S, H, T, 4);
     auto nslice = [&](uint32_t i) { DTensor t = make_dense(s.n, WRK_F16, D, T, 4); t.shape[2] = 1; t.offset[2] = i; return t; };
     auto bvec = [&](const wrk_buf* b) { return make_dense(b->ptr, WRK_F16, D, 1, 1); };
+    // WRK_MERGE_MASK (debug): 1 shifts in one pass, 2 grouped projections, 4 pre-WKV stage, 8 post-WKV stage, 16 W_o add in the epilogue
+    const char* mm_env = getenv("WRK_MERGE_MASK");
+    const unsigned mask = mm_env ? (unsigned)atoi(mm_env) : 31u;
+    const bool wide = merged && S == 64 && T > 0;     // merged element-wise stages (one wave per head and token)
+    const bool m_shift = merged && (mask & 1u), m_group = merged && (mask & 2u), m_pre = wide && (mask & 4u), m_post = wide && (mask & 8u),
+               m_res = merged && (mask & 16u);
 
     // embed: LN(ln0) in place on the gathered rows, blit to x (v7.rs:649-659)
     DTensor input = vec(s.input);
@@ -138,12 +144,21 @@ int32_t wrk_v7_model::enqueue_ops(wrk_v7_state* st, uint32_t T, uint32_t NH, boo
 
         wrk::blit(q, x, att_x);                                                          // 1
         wrk::layer_norm(q, L.ln1_w->ptr, L.ln1_b->ptr, att_x, LN_EPS);                   // 2
-        if (merged) {
-            // same arithmetic, fewer launches (mode 1, multi-token chunks): the six shifts read LN(x) once; the projections
-            // that are ready together share a launch (r, k, v, LoRA downs | LoRA ups)
+        // Mode 1 (merged): same arithmetic, fewer launches for multi-token chunks -- the six shifts read LN(x) once, the projections
+        // that are ready together share a launch (r, k, v, LoRA downs | LoRA ups), the element-wise chains run as one kernel.
+        if (m_shift) {
             const DTensor mixes[6] = {bvec(L.x_r), bvec(L.x_w), bvec(L.x_k), bvec(L.x_v), bvec(L.x_a), bvec(L.x_g)};
             const DTensor outs[6] = {rx, wx, kx, vx, ax, gx};
             wrk::token_shift_multi(q, s.cursors, mixes, outs, 6, st_row0, att_x, 1);
+        } else {
+            wrk::token_shift(q, s.cursors, bvec(L.x_r), st_row0, att_x, rx, 1);               // 3
+            wrk::token_shift(q, s.cursors, bvec(L.x_w), st_row0, att_x, wx, 1);
+            wrk::token_shift(q, s.cursors, bvec(L.x_k), st_row0, att_x, kx, 1);
+            wrk::token_shift(q, s.cursors, bvec(L.x_v), st_row0, att_x, vx, 1);
+            wrk::token_shift(q, s.cursors, bvec(L.x_a), st_row0, att_x, ax, 1);
+            wrk::token_shift(q, s.cursors, bvec(L.x_g), st_row0, att_x, gx, 1);
+        }
+        if (m_group) {
             wrk::MatJob ja[7] = {mj(L.w_r, rx, r, WRK_ACT_NONE), mj(L.w_k, kx, k, WRK_ACT_NONE), mj(L.w_v, vx, v, WRK_ACT_NONE),
                                  mj(L.w1, wx, aux_w, WRK_ACT_TANH), mj(L.a1, ax, aux_a, WRK_ACT_NONE), mj(L.g1, gx, aux_g, WRK_ACT_SIGMOID),
                                  mj(li ? L.v1 : L.a1, li ? vx : ax, li ? aux_v : aux_a, WRK_ACT_NONE)};
@@ -153,50 +168,50 @@ int32_t wrk_v7_model::enqueue_ops(wrk_v7_state* st, uint32_t T, uint32_t NH, boo
                                  mj(li ? L.v2 : L.a2, li ? aux_v : aux_a, li ? vv : a, WRK_ACT_NONE)};
             rg = mm_group(ctx, jb, li ? 4 : 3);
             if (rg != WRK_OK) return rg;
-            wrk::binary(q, 0, bvec(L.w0), w, 0, 0, 0);
-            wrk::binary(q, 0, bvec(L.a0), a, 0, 0, WRK_ACT_SIGMOID);
         } else {
-            wrk::token_shift(q, s.cursors, bvec(L.x_r), st_row0, att_x, rx, 1);               // 3
-            wrk::token_shift(q, s.cursors, bvec(L.x_w), st_row0, att_x, wx, 1);
-            wrk::token_shift(q, s.cursors, bvec(L.x_k), st_row0, att_x, kx, 1);
-            wrk::token_shift(q, s.cursors, bvec(L.x_v), st_row0, att_x, vx, 1);
-            wrk::token_shift(q, s.cursors, bvec(L.x_a), st_row0, att_x, ax, 1);
-            wrk::token_shift(q, s.cursors, bvec(L.x_g), st_row0, att_x, gx, 1);
             MM(L.w_r, rx, r, WRK_ACT_NONE);                                                  // 4
             MM(L.w_k, kx, k, WRK_ACT_NONE);
             MM(L.w_v, vx, v, WRK_ACT_NONE);
             MM(L.w1, wx, aux_w, WRK_ACT_TANH);                                               // 5
             MM(L.w2, aux_w, w, WRK_ACT_NONE);
-            wrk::binary(q, 0, bvec(L.w0), w, 0, 0, 0);
             MM(L.a1, ax, aux_a, WRK_ACT_NONE);                                               // 6
             MM(L.a2, aux_a, a, WRK_ACT_NONE);
-            wrk::binary(q, 0, bvec(L.a0), a, 0, 0, WRK_ACT_SIGMOID);
             MM(L.g1, gx, aux_g, WRK_ACT_SIGMOID);                                            // 7
             MM(L.g2, aux_g, g, WRK_ACT_NONE);
-        }
-        wrk::blit(q, k, kk);                                                             // 8
-        wrk::binary(q, 1, bvec(L.k_k), kk, 0, 0, 0);
-        wrk::l2_norm(q, heads(s.kk), L2_EPS);
-        wrk::control_k_v7(q, L.k_a->ptr, a, k);                                          // 9
-        if (li == 0) {                                                                   // 10
-            wrk::blit(q, v, v0);
-        } else {
-            if (!merged) {
+            if (li) {                                                                        // 10 (projections)
                 MM(L.v1, vx, aux_v, WRK_ACT_NONE);
                 MM(L.v2, aux_v, vv, WRK_ACT_NONE);
             }
-            wrk::binary(q, 0, bvec(L.v0), vv, 0, 0, WRK_ACT_SIGMOID);
-            wrk::lerp(q, v0, v, vv, 1);
         }
-        wrk::blit(q, k, nslice(0));                                                      // 11
-        wrk::blit(q, v, nslice(1));
-        wrk::blit(q, a, nslice(2));
-        wrk::blit(q, kk, nslice(3));
+        if (m_pre) {     // steps 5-11's element-wise ops in one launch, bit-identical (wrk_ops.hip: pre_wkv_v7)
+            wrk::pre_wkv_v7(q, s.w, s.a, s.k, s.v, s.vv, s.att_v0, s.n, L.w0->ptr, L.a0->ptr, L.k_k->ptr, L.k_a->ptr, li ? L.v0->ptr : L.a0->ptr,
+                            D, T, li == 0, L2_EPS);
+        } else {
+            wrk::binary(q, 0, bvec(L.w0), w, 0, 0, 0);                                       // 5
+            wrk::binary(q, 0, bvec(L.a0), a, 0, 0, WRK_ACT_SIGMOID);                         // 6
+            wrk::blit(q, k, kk);                                                             // 8
+            wrk::binary(q, 1, bvec(L.k_k), kk, 0, 0, 0);
+            wrk::l2_norm(q, heads(s.kk), L2_EPS);
+            wrk::control_k_v7(q, L.k_a->ptr, a, k);                                          // 9
+            if (li == 0) {                                                                   // 10
+                wrk::blit(q, v, v0);
+            } else {
+                wrk::binary(q, 0, bvec(L.v0), vv, 0, 0, WRK_ACT_SIGMOID);
+                wrk::lerp(q, v0, v, vv, 1);
+            }
+            wrk::blit(q, k, nslice(0));                                                      // 11
+            wrk::blit(q, v, nslice(1));
+            wrk::blit(q, a, nslice(2));
+            wrk::blit(q, kk, nslice(3));
+        }
         wrk::time_mix_v7(q, s.cursors, st_att, heads(s.r), heads(s.w), n4, heads(s.att_x));   // 12
-        wrk::group_norm(q, L.gn_w->ptr, L.gn_b->ptr, heads(s.att_x), GN_EPS);            // 13
-        wrk::time_first_v7(q, L.r_k->ptr, heads(s.r), n4, heads(s.att_x));               // 14
-        wrk::binary(q, 1, g, att_x, 0, 0, 0);                                            // 15
-        if (merged) {       // the add rides the projection's epilogue: x = round(W_o att_x) + x
+        if (m_post) wrk::post_wkv_v7(q, s.att_x, s.r, s.g, s.n, L.gn_w->ptr, L.gn_b->ptr, L.r_k->ptr, D, T, GN_EPS);    // 13-15 in one launch
+        else {
+            wrk::group_norm(q, L.gn_w->ptr, L.gn_b->ptr, heads(s.att_x), GN_EPS);        // 13
+            wrk::time_first_v7(q, L.r_k->ptr, heads(s.r), n4, heads(s.att_x));           // 14
+            wrk::binary(q, 1, g, att_x, 0, 0, 0);                                        // 15
+        }
+        if (m_res) {        // the add rides the projection's epilogue: x = round(W_o att_x) + x
             wrk::MatJob jo = mj(L.w_o, att_x, x, WRK_ACT_NONE);
             jo.has_res = 1;
             jo.res = x;
