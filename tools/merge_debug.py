@@ -21,7 +21,7 @@ def run(mode, mask):
     return l[0], st
 
 ref, rst = run(0, 0)
-for mask in (0, 1, 2, 4, 8, 16, 31):
+for mask in (0, 1, 2, 4, 8, 16, 32, 64, 127):
     l, st = run(1, mask)
     d = np.abs(l - ref)
     rows = np.nonzero(d.max(axis=1))[0]

@@ -125,6 +125,7 @@ namespace wrk {
 
 // wrk_ops.hip
 void layer_norm(hipStream_t s, const void* w, const void* b, DTensor x, float eps);
+void layer_norm_from(hipStream_t s, const void* w, const void* b, DTensor src, DTensor x, float eps);     // x = LN(src), same shapes
 void group_norm(hipStream_t s, const void* w, const void* b, DTensor x, float eps);
 void l2_norm(hipStream_t s, DTensor x, float eps);
 void token_shift(hipStream_t s, const uint32_t* cursors, DTensor mix, DTensor state, DTensor in, DTensor out, int reversed);

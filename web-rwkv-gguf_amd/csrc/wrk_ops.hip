@@ -12,22 +12,22 @@ namespace wrk {
 // shaders/layer_norm.wgsl:63-121.  One workgroup per row; statistics two-pass in f32
 // (mean, then centred second moment: same quantities as the shader's Welford merge).
 template <int BLOCK>
-__global__ void __launch_bounds__(BLOCK) layer_norm_kernel(const f16* __restrict__ w, const f16* __restrict__ b, DTensor x,
+__global__ void __launch_bounds__(BLOCK) layer_norm_kernel(const f16* __restrict__ w, const f16* __restrict__ b, DTensor src, DTensor x,
                                                             float eps, int group) {
     __shared__ float red[BLOCK / 64];
     const uint32_t C = x.shape[0];
     const uint32_t token = blockIdx.x, batch = blockIdx.y;
-    const size_t base = dt_index(x, 0, token, batch);
+    const size_t base = dt_index(x, 0, token, batch), sbase = dt_index(src, 0, token, batch);      // src == x: in place
     const uint32_t wofs = group ? token * C : 0;    // GROUP_NORM: h = token * stride
     float s = 0.0f;
-    for (uint32_t i = threadIdx.x; i < C; i += BLOCK) s += dt_load(x, base + i);
+    for (uint32_t i = threadIdx.x; i < C; i += BLOCK) s += dt_load(src, sbase + i);
     const float mean = block_sum<BLOCK / 64>(s, red) / (float)C;
     float q = 0.0f;
-    for (uint32_t i = threadIdx.x; i < C; i += BLOCK) { float d = dt_load(x, base + i) - mean; q += d * d; }
+    for (uint32_t i = threadIdx.x; i < C; i += BLOCK) { float d = dt_load(src, sbase + i) - mean; q += d * d; }
     const float var = block_sum<BLOCK / 64>(q, red) / (float)C + eps;
     const float dev = 1.0f / sqrtf(var);
     for (uint32_t i = threadIdx.x; i < C; i += BLOCK) {
-        float value = (dt_load(x, base + i) - mean) * dev;
+        float value = (dt_load(src, sbase + i) - mean) * dev;
         dt_store(x, base + i, __builtin_fmaf(value, (float)w[wofs + i], (float)b[wofs + i]));
     }
 }
@@ -35,14 +35,21 @@ __global__ void __launch_bounds__(BLOCK) layer_norm_kernel(const f16* __restrict
 void layer_norm(hipStream_t s, const void* w, const void* b, DTensor x, float eps) {
     dim3 grid(x.shape[1], x.shape[2]);
     if (grid.x == 0 || grid.y == 0) return;
-    layer_norm_kernel<256><<<grid, 256, 0, s>>>((const f16*)w, (const f16*)b, x, eps, 0);
+    layer_norm_kernel<256><<<grid, 256, 0, s>>>((const f16*)w, (const f16*)b, x, x, eps, 0);
+}
+
+// blit(src, x) + layer_norm(x) in one pass (the copy is exact, so the result is the same)
+void layer_norm_from(hipStream_t s, const void* w, const void* b, DTensor src, DTensor x, float eps) {
+    dim3 grid(x.shape[1], x.shape[2]);
+    if (grid.x == 0 || grid.y == 0) return;
+    layer_norm_kernel<256><<<grid, 256, 0, s>>>((const f16*)w, (const f16*)b, src, x, eps, 0);
 }
 
 void group_norm(hipStream_t s, const void* w, const void* b, DTensor x, float eps) {
     // x [S, H, T]: "token" = head, "batch" = token (ops.rs:460-508)
     dim3 grid(x.shape[1], x.shape[2]);
     if (grid.x == 0 || grid.y == 0) return;
-    layer_norm_kernel<64><<<grid, 64, 0, s>>>((const f16*)w, (const f16*)b, x, eps, 1);
+    layer_norm_kernel<64><<<grid, 64, 0, s>>>((const f16*)w, (const f16*)b, x, x, eps, 1);
 }
 
 // ------------------------------------------------------------------ l2_norm (normalize.wgsl:117-152)

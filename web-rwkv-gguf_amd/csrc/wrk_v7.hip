@@ -121,12 +121,13 @@ int32_t wrk_v7_model::enqueue_ops(wrk_v7_state* st, uint32_t T, uint32_t NH, boo
     DTensor n4 = make_dense(s.n, WRK_F16, S, H, T, 4);
     auto nslice = [&](uint32_t i) { DTensor t = make_dense(s.n, WRK_F16, D, T, 4); t.shape[2] = 1; t.offset[2] = i; return t; };
     auto bvec = [&](const wrk_buf* b) { return make_dense(b->ptr, WRK_F16, D, 1, 1); };
-    // WRK_MERGE_MASK (debug): 1 shifts in one pass, 2 grouped projections, 4 pre-WKV stage, 8 post-WKV stage, 16 W_o add in the epilogue
+    // WRK_MERGE_MASK (debug): 1 shifts in one pass, 2 grouped projections, 4 pre-WKV stage, 8 post-WKV stage, 16 W_o add in the epilogue,
+    // 32 blit + layer_norm in one pass, 64 ffn.value's add in the epilogue
     const char* mm_env = getenv("WRK_MERGE_MASK");
-    const unsigned mask = mm_env ? (unsigned)atoi(mm_env) : 31u;
+    const unsigned mask = mm_env ? (unsigned)atoi(mm_env) : 127u;
     const bool wide = merged && S == 64 && T > 0;     // merged element-wise stages (one wave per head and token)
     const bool m_shift = merged && (mask & 1u), m_group = merged && (mask & 2u), m_pre = wide && (mask & 4u), m_post = wide && (mask & 8u),
-               m_res = merged && (mask & 16u);
+               m_res = merged && (mask & 16u), m_ln = merged && (mask & 32u), m_tail = merged && (mask & 64u);
 
     // embed: LN(ln0) in place on the gathered rows, blit to x (v7.rs:649-659)
     DTensor input = vec(s.input);
@@ -142,8 +143,11 @@ int32_t wrk_v7_model::enqueue_ops(wrk_v7_state* st, uint32_t T, uint32_t NH, boo
         DTensor st_ffn = make_dense(st->layer_ptr(li), WRK_F32, D, S + 2, st->num_batch);
         st_ffn.shape[1] = 1; st_ffn.offset[1] = S + 1;
 
-        wrk::blit(q, x, att_x);                                                          // 1
-        wrk::layer_norm(q, L.ln1_w->ptr, L.ln1_b->ptr, att_x, LN_EPS);                   // 2
+        if (m_ln) wrk::layer_norm_from(q, L.ln1_w->ptr, L.ln1_b->ptr, x, att_x, LN_EPS);     // 1-2 in one pass
+        else {
+            wrk::blit(q, x, att_x);                                                      // 1
+            wrk::layer_norm(q, L.ln1_w->ptr, L.ln1_b->ptr, att_x, LN_EPS);               // 2
+        }
         // Mode 1 (merged): same arithmetic, fewer launches for multi-token chunks -- the six shifts read LN(x) once, the projections
         // that are ready together share a launch (r, k, v, LoRA downs | LoRA ups), the element-wise chains run as one kernel.
         if (m_shift) {
@@ -221,13 +225,25 @@ int32_t wrk_v7_model::enqueue_ops(wrk_v7_state* st, uint32_t T, uint32_t NH, boo
             MM(L.w_o, att_x, o, WRK_ACT_NONE);                                           // 16
             wrk::binary(q, 0, o, x, 0, 0, 0);
         }
-        wrk::blit(q, x, ffn_x);                                                          // 17
-        wrk::layer_norm(q, L.ln2_w->ptr, L.ln2_b->ptr, ffn_x, LN_EPS);
+        if (m_ln) wrk::layer_norm_from(q, L.ln2_w->ptr, L.ln2_b->ptr, x, ffn_x, LN_EPS);
+        else {
+            wrk::blit(q, x, ffn_x);                                                      // 17
+            wrk::layer_norm(q, L.ln2_w->ptr, L.ln2_b->ptr, ffn_x, LN_EPS);
+        }
         wrk::token_shift(q, s.cursors, bvec(L.ffn_x_k), st_ffn, ffn_x, ffn_kx, 1);        // 18
         MM(L.ffn_w_k, ffn_kx, ffn_k, WRK_ACT_SQUARED_RELU);                              // 19
-        MM(L.ffn_w_v, ffn_k, ffn_v, WRK_ACT_NONE);                                       // 20
-        wrk::channel_mix_v7(q, s.cursors, st_ffn, ffn_v, ffn_x);                         // 21
-        wrk::binary(q, 0, ffn_x, x, 0, 0, 0);                                            // 22
+        if (m_tail) {       // x = round(W_v k) + x in the epilogue; channel_mix still saves the ffn shift state (its copy is dead)
+            wrk::MatJob jv = mj(L.ffn_w_v, ffn_k, x, WRK_ACT_NONE);
+            jv.has_res = 1;
+            jv.res = x;
+            const int32_t rg = mm_group(ctx, &jv, 1);
+            if (rg != WRK_OK) return rg;
+            wrk::channel_mix_v7(q, s.cursors, st_ffn, ffn_v, ffn_x);
+        } else {
+            MM(L.ffn_w_v, ffn_k, ffn_v, WRK_ACT_NONE);                                   // 20
+            wrk::channel_mix_v7(q, s.cursors, st_ffn, ffn_v, ffn_x);                     // 21
+            wrk::binary(q, 0, ffn_x, x, 0, 0, 0);                                        // 22
+        }
         if ((li + 1) % d.rescale == 0) wrk::affine(q, x, 0.5f, 0.0f);                    // 23
     }
     // header (v7.rs:1009-1036): gather header rows, LN(ln_out), head matmul into f32 logits
