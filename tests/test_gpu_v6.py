@@ -162,3 +162,23 @@ def test_v6_fused_decode_matches_op_by_op_and_oracle(ctx, B, mat):
         toks = [int(ol[b].argmax()) for b in range(B)]
         assert t1[step].tolist() == toks, step
     rt1.close(); rt0.close()
+
+
+def test_v6_merged_prefill_launches_are_bit_identical_to_the_op_list(ctx):
+    """Mode 1 runs a multi-token RWKV-6 chunk with fewer launches (blit + LN in one pass, the five LoRA ups / the five
+    att projections / ffn key + receptance grouped into one MFMA launch each, W_o's add in the epilogue, both ffn shifts
+    in one pass).  Same arithmetic, so above 64 stacked tokens logits and state must equal mode 0's exactly."""
+    cfg = synth.V6_CONFIGS["small"]
+    data = synth.make_v6_gguf(cfg, 5, mat="Q4_K")
+    V = cfg.num_vocab
+    p0, p1 = synth.tokens(9, "v6m-a", 70, V), synth.tokens(9, "v6m-b", 26, V)
+    out = []
+    for mode in (0, 1):
+        rt = wrk.Runtime(ctx, wrk.GgufReader(data), num_batch=2, weights=wrk.WEIGHTS_INLINE)
+        a = rt.infer(wrk.RnnInput([p0, p1], 96, [wrk.RNN_FULL, wrk.RNN_LAST]), mode=mode)
+        b = rt.infer(wrk.RnnInput([[3] * 40, [5] * 33], 128), mode=mode)
+        out.append((a + b, rt.state_back(0), rt.state_back(1)))
+        rt.close()
+    for x, y in zip(out[0][0], out[1][0]):
+        assert np.array_equal(x, y), float(np.abs(x - y).max())
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])

@@ -28,10 +28,15 @@ def main():
     ap.add_argument("--mixed", action="store_true", help="llama.cpp Q4_K_M type mix (Q6_K for half the value matrices and the head)")
     a = ap.parse_args()
     import wrk
-    L, D, F, V, lw, la, lv, lg = bench.CONFIGS[a.model]
     ctx = wrk.Context(0)
-    rt = wrk.Runtime(ctx, wrk.GgufReader(bench.make_model_gguf(a.model, seed=42, mixed=a.mixed)), num_batch=a.batch, weights=wrk.WEIGHTS_INLINE)
-    flop_tok = 2.0 * (12.0 * D * D * L + L * 2.0 * D * (lw + la + lg) + (L - 1) * 2.0 * D * lv)
+    if a.model in bench.CONFIGS_V6:         # RWKV-6 (cfg 4 / 5 models): 5 D^2 att + 2 D F + D^2 ffn matrices, two LoRA stacks
+        L, D, F, V, R, W = bench.CONFIGS_V6[a.model]
+        rt = wrk.Runtime(ctx, wrk.GgufReader(bench.make_model_gguf_v6(a.model, seed=42)), num_batch=a.batch, weights=wrk.WEIGHTS_INLINE)
+        flop_tok = 2.0 * L * (6.0 * D * D + 2.0 * D * F + 10.0 * D * R + 2.0 * D * W)
+    else:
+        L, D, F, V, lw, la, lv, lg = bench.CONFIGS[a.model]
+        rt = wrk.Runtime(ctx, wrk.GgufReader(bench.make_model_gguf(a.model, seed=42, mixed=a.mixed)), num_batch=a.batch, weights=wrk.WEIGHTS_INLINE)
+        flop_tok = 2.0 * (12.0 * D * D * L + L * 2.0 * D * (lw + la + lg) + (L - 1) * 2.0 * D * lv)
     best = None
     for rep in range(a.repeat + 1):
         toks = [[(7 + 13 * i + 101 * b + rep) % (V - 1) for i in range(a.prompt)] for b in range(a.batch)]
@@ -47,7 +52,7 @@ def main():
         if rep and (best is None or dt < best):
             best = dt
     total = a.prompt * a.batch
-    print(json.dumps({"workload": f"RWKV-7 {a.model} {'Q4_K_M mix' if a.mixed else 'Q4_K'} prefill, {a.batch} x {a.prompt} tokens, chunk {a.chunk}", "chunks": n,
+    print(json.dumps({"workload": f"{'RWKV-6' if a.model in bench.CONFIGS_V6 else 'RWKV-7'} {a.model} {'Q5_K_M' if a.model in bench.CONFIGS_V6 else ('Q4_K_M mix' if a.mixed else 'Q4_K')} prefill, {a.batch} x {a.prompt} tokens, chunk {a.chunk}", "chunks": n,
                       "tokens_per_s": round(total / best, 1), "ms": round(best * 1e3, 3),
                       "matrix_TFLOPs": round(total * flop_tok / best / 1e12, 2), "mfma_peak_TFLOPs_f16_dense": 2500.0}))
 

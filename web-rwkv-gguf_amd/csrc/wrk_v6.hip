@@ -30,7 +30,7 @@ struct wrk_v6_model {
     void drop_graphs() { for (auto& kv : graphs) wrk_program_destroy(kv.second); graphs.clear(); }
     int32_t ensure_scratch(uint32_t T, uint32_t NH);
     int32_t ensure_history(size_t n);
-    int32_t enqueue_ops(wrk_v7_state* st, uint32_t T, uint32_t NH, bool identity);
+    int32_t enqueue_ops(wrk_v7_state* st, uint32_t T, uint32_t NH, bool identity, bool merged = false);
     int32_t enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_t NH, bool identity, uint32_t batch0);
 };
 
@@ -89,8 +89,26 @@ static int32_t mm6(wrk_ctx* ctx, const wrk_matrix* m, DTensor in, DTensor out, u
     return WRK_OK;
 }
 #define MM(...) do { int32_t _r = mm6(ctx, __VA_ARGS__); if (_r != WRK_OK) return _r; } while (0)
+static wrk::MatJob job6m(const wrk_matrix* m, DTensor in, DTensor out, uint32_t act) {
+    wrk::MatJob j{m->data, m->aux, m->kind, m->flags, m->k, m->m, (uint32_t)m->row_bytes, in, out, act, 0};
+    j.scale = m->out_scale;
+    return j;
+}
+// several matrices x the same token count in one MFMA launch per kernel family; per-matrix launches when the GEMM declines
+static int32_t mm6_group(wrk_ctx* ctx, wrk::MatJob* jobs, int n) {
+    const uint32_t T = jobs[0].in.shape[1] * jobs[0].in.shape[2];
+    if (T >= wrk::gemm_min_tokens() && wrk::matmul_mfma_multi(ctx->stream, jobs, n, ctx->num_cu) == 0) return WRK_OK;
+    for (int i = 0; i < n; ++i) {
+        int rc = -2;
+        if (T >= wrk::gemm_min_tokens()) rc = wrk::matmul_mfma(ctx->stream, jobs[i], ctx->num_cu);
+        if (rc == -2) rc = wrk::matvec(ctx->stream, &jobs[i], 1, ctx->num_cu);
+        if (rc != 0) return wrk_fail(ctx, WRK_E_ARG, "matmul launch rejected (K=%u M=%u rc=%d)", jobs[i].k, jobs[i].m, rc);
+    }
+    return WRK_OK;
+}
+#define MMG(jobs, n) do { int32_t _r = mm6_group(ctx, jobs, n); if (_r != WRK_OK) return _r; } while (0)
 
-int32_t wrk_v6_model::enqueue_ops(wrk_v7_state* st, uint32_t T, uint32_t NH, bool identity) {
+int32_t wrk_v6_model::enqueue_ops(wrk_v7_state* st, uint32_t T, uint32_t NH, bool identity, bool merged) {
     hipStream_t q = ctx->stream;
     const uint32_t D = d.num_emb, F = d.num_hidden, H = d.num_head, S = D / H, V = d.num_vocab, R = d.time_mix, W = d.time_decay;
     auto vec = [&](void* p, uint32_t c = 0, uint32_t dt = WRK_F16) { return make_dense(p, dt, c ? c : D, T); };
@@ -113,20 +131,37 @@ int32_t wrk_v6_model::enqueue_ops(wrk_v7_state* st, uint32_t T, uint32_t NH, boo
         DTensor st_ffn = make_dense(st->layer_ptr(li), WRK_F32, D, S + 2, st->num_batch);
         st_ffn.shape[1] = 1; st_ffn.offset[1] = S + 1;
 
-        wrk::blit(q, x, att_x);
-        wrk::layer_norm(q, L.ln1_w->ptr, L.ln1_b->ptr, att_x, LN_EPS);
+        // merged (mode 1, multi-token chunks): the same arithmetic in fewer launches -- blit + LN in one pass, the projections that
+        // are ready together in one MFMA launch, W_o's add in the epilogue; results are bit-identical to the op list
+        if (merged) wrk::layer_norm_from(q, L.ln1_w->ptr, L.ln1_b->ptr, x, att_x, LN_EPS);
+        else {
+            wrk::blit(q, x, att_x);
+            wrk::layer_norm(q, L.ln1_w->ptr, L.ln1_b->ptr, att_x, LN_EPS);
+        }
         wrk::token_shift(q, s.cursors, bvec(L.time_mix_x), st_row0, att_x, att_xx, 1);
         MM(L.time_mix_w1, att_xx, make_dense(s.tmx, WRK_F16, R * 5, T), WRK_ACT_TANH);                     // time_mix_x [R, 5, T] seen as [5R, T]
         wrk::transpose(q, make_dense(s.tmx, WRK_F16, R, 5, T), make_dense(s.tmt, WRK_F16, R, T, 5));
-        for (uint32_t i = 0; i < 5; ++i)                                                                  // batched [R, D, 5] matmul
-            MM(L.time_mix_w2[i], slice(make_dense(s.tmt, WRK_F16, R, T, 5), i), slice(tm5, i), WRK_ACT_NONE);
+        if (merged) {
+            wrk::MatJob jw[5];
+            for (uint32_t i = 0; i < 5; ++i) jw[i] = job6m(L.time_mix_w2[i], slice(make_dense(s.tmt, WRK_F16, R, T, 5), i), slice(tm5, i), WRK_ACT_NONE);
+            MMG(jw, 5);
+        } else
+            for (uint32_t i = 0; i < 5; ++i)                                                              // batched [R, D, 5] matmul
+                MM(L.time_mix_w2[i], slice(make_dense(s.tmt, WRK_F16, R, T, 5), i), slice(tm5, i), WRK_ACT_NONE);
         wrk::binary(q, 0, make_dense(L.time_mix->ptr, WRK_F16, D, 1, 5), tm5, 0, 0, 0);                    // add(time_mix, buffer.time_mix)
         wrk::token_shift(q, s.cursors, tm5, st_row0, att_x, sx5, 1);
-        MM(L.w_k, slice(sx5, 1), att_k, WRK_ACT_NONE);
-        MM(L.w_v, slice(sx5, 2), att_v, WRK_ACT_NONE);
-        MM(L.w_r, slice(sx5, 3), att_r, WRK_ACT_NONE);
-        MM(L.w_g, slice(sx5, 4), att_g, WRK_ACT_NONE);
-        MM(L.time_decay_w1, slice(sx5, 0), att_w, WRK_ACT_TANH);
+        if (merged) {
+            wrk::MatJob jp[5] = {job6m(L.w_k, slice(sx5, 1), att_k, WRK_ACT_NONE), job6m(L.w_v, slice(sx5, 2), att_v, WRK_ACT_NONE),
+                                 job6m(L.w_r, slice(sx5, 3), att_r, WRK_ACT_NONE), job6m(L.w_g, slice(sx5, 4), att_g, WRK_ACT_NONE),
+                                 job6m(L.time_decay_w1, slice(sx5, 0), att_w, WRK_ACT_TANH)};
+            MMG(jp, 5);
+        } else {
+            MM(L.w_k, slice(sx5, 1), att_k, WRK_ACT_NONE);
+            MM(L.w_v, slice(sx5, 2), att_v, WRK_ACT_NONE);
+            MM(L.w_r, slice(sx5, 3), att_r, WRK_ACT_NONE);
+            MM(L.w_g, slice(sx5, 4), att_g, WRK_ACT_NONE);
+            MM(L.time_decay_w1, slice(sx5, 0), att_w, WRK_ACT_TANH);
+        }
         MM(L.time_decay_w2, att_w, tdec, WRK_ACT_NONE);
         wrk::binary(q, 0, bvec(L.time_decay), tdec, 0, 0, 0);
         wrk::activate(q, tdec, WRK_ACT_STABLE_EXP);
@@ -136,16 +171,29 @@ int32_t wrk_v6_model::enqueue_ops(wrk_v7_state* st, uint32_t T, uint32_t NH, boo
         wrk::group_norm(q, L.gn_w->ptr, L.gn_b->ptr, heads(s.aux_x), GN_EPS);
         wrk::blit(q, aux_x, att_x);
         wrk::binary(q, 1, att_g, att_x, WRK_ACT_SILU, 0, 0);                                              // mul_activate(att_g Silu, att_x)
-        MM(L.w_o, att_x, att_o, WRK_ACT_NONE);
-        wrk::binary(q, 0, att_o, x, 0, 0, 0);
+        if (merged) {
+            wrk::MatJob jo = job6m(L.w_o, att_x, x, WRK_ACT_NONE);       // x = round(W_o att_x) + x
+            jo.has_res = 1;
+            jo.res = x;
+            MMG(&jo, 1);
+            wrk::layer_norm_from(q, L.ln2_w->ptr, L.ln2_b->ptr, x, ffn_x, LN_EPS);
+            const DTensor fm[2] = {bvec(L.ffn_mix_k), bvec(L.ffn_mix_r)}, fo[2] = {ffn_kx, ffn_rx};
+            wrk::token_shift_multi(q, s.cursors, fm, fo, 2, st_ffn, ffn_x, 1);
+            wrk::MatJob jf[2] = {job6m(L.ffn_w_k, ffn_kx, ffn_k, WRK_ACT_SQUARED_RELU), job6m(L.ffn_w_r, ffn_rx, ffn_r, WRK_ACT_NONE)};
+            MMG(jf, 2);
+            MM(L.ffn_w_v, ffn_k, ffn_v, WRK_ACT_NONE);
+        } else {
+            MM(L.w_o, att_x, att_o, WRK_ACT_NONE);
+            wrk::binary(q, 0, att_o, x, 0, 0, 0);
 
-        wrk::blit(q, x, ffn_x);
-        wrk::layer_norm(q, L.ln2_w->ptr, L.ln2_b->ptr, ffn_x, LN_EPS);
-        wrk::token_shift(q, s.cursors, bvec(L.ffn_mix_k), st_ffn, ffn_x, ffn_kx, 1);
-        wrk::token_shift(q, s.cursors, bvec(L.ffn_mix_r), st_ffn, ffn_x, ffn_rx, 1);
-        MM(L.ffn_w_k, ffn_kx, ffn_k, WRK_ACT_SQUARED_RELU);
-        MM(L.ffn_w_v, ffn_k, ffn_v, WRK_ACT_NONE);
-        MM(L.ffn_w_r, ffn_rx, ffn_r, WRK_ACT_NONE);
+            wrk::blit(q, x, ffn_x);
+            wrk::layer_norm(q, L.ln2_w->ptr, L.ln2_b->ptr, ffn_x, LN_EPS);
+            wrk::token_shift(q, s.cursors, bvec(L.ffn_mix_k), st_ffn, ffn_x, ffn_kx, 1);
+            wrk::token_shift(q, s.cursors, bvec(L.ffn_mix_r), st_ffn, ffn_x, ffn_rx, 1);
+            MM(L.ffn_w_k, ffn_kx, ffn_k, WRK_ACT_SQUARED_RELU);
+            MM(L.ffn_w_v, ffn_k, ffn_v, WRK_ACT_NONE);
+            MM(L.ffn_w_r, ffn_rx, ffn_r, WRK_ACT_NONE);
+        }
         wrk::channel_mix_v6(q, s.cursors, st_ffn, ffn_r, ffn_v, ffn_x);
         wrk::binary(q, 0, ffn_x, x, 0, 0, 0);
         if ((li + 1) % d.rescale == 0) wrk::affine(q, x, 0.5f, 0.0f);                                     // v6.rs:953-955
@@ -594,7 +642,7 @@ int32_t wrk_v6_infer(wrk_ctx* ctx, wrk_v6_model* m, wrk_v7_state* st, const uint
     }
     rc = WRK_E_UNSUPPORTED;
     if (mode == 1 && one_token_each) rc = m->enqueue_fused_decode(st, T, NH, identity, cursors[0] & 0xff);
-    if (rc == WRK_E_UNSUPPORTED) rc = m->enqueue_ops(st, T, NH, identity);
+    if (rc == WRK_E_UNSUPPORTED) rc = m->enqueue_ops(st, T, NH, identity, mode == 1 && !one_token_each);
     if (rc != WRK_OK) return rc;
     if (NH && argmax) wrk::argmax_rows(ctx->stream, m->s.head_o, V, V, NH, m->s.argmax);
     WRK_LAUNCH_CHECK(ctx);
