@@ -265,7 +265,11 @@ int32_t wrk_v7_state_write(wrk_ctx* ctx, wrk_v7_state* state, uint32_t batch, co
  *   headers    stacked row indices fed to the head (RnnRedirect::headers, rnn.rs:41-81)
  *   logits     host f32 [num_vocab, num_header] or NULL
  *   argmax     host u32 [num_header] or NULL (greedy token per header row, computed on device)
- *   mode       0 = op-by-op (one kernel per reference TensorOp), 1 = fused kernels
+ *   mode       0 = op-by-op (one kernel per reference TensorOp, the launch list of v7.rs:716-1007);
+ *              1 = fast paths: one token per sequence -> the fused 5-launch decode layer; multi-token chunks -> the
+ *                  same op list with merged launches (six shifts in one pass, projections grouped per stage, the
+ *                  element-wise chains around the WKV kernel as one kernel each, residual adds in the GEMM epilogue),
+ *                  whose logits and state are bit-identical to mode 0 above 64 stacked tokens
  */
 int32_t wrk_v7_infer(wrk_ctx* ctx, wrk_v7_model* model, wrk_v7_state* state,
                      const uint32_t* tokens, const uint16_t* emb_rows, const uint32_t* cursors, uint32_t num_token,
