@@ -135,7 +135,8 @@ def test_gemm_activation_residual_f16_out_and_vec_agreement(ctx):
     ("Q4_K", 2048, 130, 200), ("Q5_K", 1024, 200, 100), ("Q4_K", 256, 64, 48), ("Q6_K", 2560, 72, 64),
     ("Q4_K", 2048, 520, 500), ("Q5_K", 1024, 1030, 250), ("Q4_K", 256, 2050, 130), ("Q5_K", 2560, 520, 470),
     ("Q6_K", 2048, 520, 500), ("Q6_K", 768, 1030, 250), ("Q6_K", 4096, 1100, 400), ("Q6_K", 256, 2050, 130),
-    ("F16", 2048, 520, 500), ("F16", 96, 2050, 130), ("Q4_K", 4096, 1100, 400)])
+    ("F16", 2048, 520, 500), ("F16", 96, 2050, 130), ("Q4_K", 4096, 1100, 400),
+    ("F16", 2048, 96, 128), ("F16", 2560, 320, 70), ("F16", 2048, 64, 48)])      # LoRA down-projections: tiled whatever their tile count
 def test_gemm_prefill_tile_kernel(ctx, kind, k, m, T):
     """The LDS-tiled prefill kernel (>= 48 stacked tokens of one dense [K, T, 1] stack, >= 64 rows, Q4_K / Q5_K / Q6_K / F16):
     ragged row and token tails, fused activation with f16 output."""

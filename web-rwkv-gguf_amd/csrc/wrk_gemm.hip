@@ -904,7 +904,9 @@ int matmul_mfma_multi(hipStream_t s, const MatJob* jobs, int njobs, int) {
         // matrix x 128 tokens has only 64 tiles and is faster on the K-split kernel: 44 vs 74 us)
         const uint32_t tiles = ((j.m + TILE_ROWS - 1) / TILE_ROWS) * ((n + TILE_TOK - 1) / TILE_TOK);
         const bool tile = use_tile && n >= 48 && (j.kind == WRK_MAT_Q4_K || j.kind == WRK_MAT_Q5_K || j.kind == WRK_MAT_Q6_K || j.kind == WRK_MAT_F16) && j.m >= 64 &&
-                          j.in.shape[2] == 1 && (tiles >= 96 || (j.k <= 2560 && tiles >= 64));     // enough workgroups, or a short serial walk
+                          j.in.shape[2] == 1 && (tiles >= 96 || (j.k <= 2560 && tiles >= 64) ||    // enough workgroups, or a short serial walk,
+                                                 (j.kind == WRK_MAT_F16 && j.k <= 2560));          // or a LoRA down-projection (64..320 rows): a handful of
+        // tiles that ride along with the big matrices of their stage; on the K-split kernel they were a 32-us launch of 64 workgroups per layer
         if (tile) { fill_job(T.jobs[T.njobs++], j, n, twg); twg += (j.m + TILE_ROWS - 1) / TILE_ROWS; }
         else { fill_job(B.jobs[B.njobs++], j, n, wg); wg += (j.m + 15) / 16; kmax = j.k > kmax ? j.k : kmax; }
     }
