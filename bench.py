@@ -10,13 +10,18 @@ Weights are random-initialised blocks of the 1.5B architecture (no network for c
 Q4_K for the twelve big matrices per layer, Q6_K head, F16 embedding table, F32 LoRA/vectors
 (converted to f16 at load, as the reference does) -- the BASELINE.md section 2 byte tally.
 
-N > 1: one process per GPU (torch.distributed launcher env), every rank runs its own independent
-stream(s) on a full weight replica; no collective on the data path, barrier-bracketed
-timing, max over ranks, value = streams * steps / time  ("scaling": "weak").
+N > 1: one process per GPU, every rank runs its own independent stream(s) (global stream ids
+`replicas.partition_streams`) on a full weight replica; no collective on the data path,
+barrier-bracketed timing, max over ranks, value = streams * steps / time  ("scaling": "weak").
+`python bench.py --gpus N` with no launcher environment spawns the N ranks ITSELF (fresh child
+processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, started before the parent touches any GPU; the
+parent only forwards rank 0's JSON line); under `torch.distributed.run` (RANK already set) it is one of the ranks.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,20 +31,27 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "web-rwkv-gguf_amd"))
 
-HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy rate ~6.3 TB/s
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_MEASURED_GBS = 6290.0   # float4 copy rate measured on MI355X (same guide, chip-level parameters)
+
+
+PMC_PROFILES = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")      # newest first
 
 
 def measured_traffic(model, batch, mode):
-    """HBM bytes per decode step from the committed PMC run of this same command
-    (profiles/r01_pmc_traffic.json, made by tools/pmc_summary.py from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-    passes; counters cannot be read from inside the process).  None when no matching profile exists."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if not (model == "1.5B" and batch == 1 and mode == 1 and os.path.exists(path)):
-        return None
-    try:
-        return int(json.load(open(path))["hbm_bytes_per_step"])
-    except Exception:
-        return None
+    """(HBM bytes per decode step, source) from the committed PMC run of this same command (profiles/rNN_pmc_traffic.json,
+    made by tools/pmc_summary.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes: hardware counters cannot be
+    read from inside the process, so this figure is STATIC -- the JSON line says so in `traffic_source`).
+    (None, None) when no profile of this model / batch / mode exists."""
+    if not (model == "1.5B" and batch == 1 and mode == 1):
+        return None, None
+    for name in PMC_PROFILES:
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            return int(json.load(open(path))["hbm_bytes_per_step"]), f"profiles/{name} (static: rocprofv3 --pmc run of this command, not measured in this run)"
+        except Exception:
+            continue
+    return None, None
 
 CONFIGS = {     # SURVEY section 8 table: L, D, F, V, lora w/a/v/g
     "tiny": (2, 256, 1024, 512, 32, 32, 32, 64),
@@ -249,6 +261,45 @@ def cpu_baseline(gguf_bytes, first_token, seconds=15.0):
     return cport.time_decode(gguf_bytes, first_token, seconds)
 
 
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_replicas(n, argv):
+    """`bench.py --gpus N` without a launcher environment: spawn the N ranks as fresh child processes (one per GPU) BEFORE
+    this process touches any GPU -- the parent never imports wrk or torch.cuda -- and forward rank 0's JSON line.
+    Children get RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT exactly as torch.distributed.run sets them."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    for line in out.decode().splitlines():      # the JSON line to stdout; library chatter (e.g. gloo's connection notes) to stderr
+        (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line + "\n")
+    sys.stdout.flush()
+    if any(rcs):
+        sys.stderr.write(f"bench.py: rank exit codes {rcs}\n")
+        return 1
+    return 0
+
+
+def metric_name(model, batch, world):
+    """BASELINE.json's metric string for the headline workload; the same wording with the model / quantisation / stream
+    count actually run for every other configuration."""
+    fam, size, quant = ("RWKV-6", model[3:], "Q8_0" if model == "v6-14B" else "Q5_K_M") if model in CONFIGS_V6 else ("RWKV-7", model, "Q4_K_M")
+    streams = "" if batch == 1 else f" batch={batch}/GPU"
+    return f"tokens/sec {fam} {size} {quant} decode{streams} @{world} GPU; achieved HBM GB/s vs roofline"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -260,23 +311,57 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--quant", default="", help="ModelBuilder::quant map, e.g. int8:0-29,nf4:30-60 (layers inclusive)")
     ap.add_argument("--mixed", action="store_true", help="llama.cpp Q4_K_M tensor mix: Q6_K for attn value / ffn value in about half of the layers")
+    ap.add_argument("--stub-device", action="store_true",
+                    help="TEST ONLY (tests/test_bench_launcher.py): exercise the launcher, the rank rendezvous (gloo) and the aggregation "
+                         "without a GPU; the decode step is replaced by a sleep and the JSON line is marked \"data\": \"stub\"")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_replicas(args.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
     dist = None
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.stub_device:
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    sys.path.insert(0, os.path.join(ROOT, "web-rwkv-gguf_amd", "wrk"))
+    import replicas         # no GPU dependency (the stub ranks import nothing else of the package)
+    group = replicas.ReplicaGroup(dist, device="cuda" if (dist is not None and not args.stub_device) else None)
+    B = args.batch
+    streams = group.my_streams(world * B)           # global ids of the independent sequences this rank owns
+    assert len(streams) == B
+
+    if args.stub_device:
+        group.barrier()
+        t0 = time.perf_counter()
+        time.sleep(0.001 * args.steps * (1 + 0.1 * rank))
+        dev_ms = (time.perf_counter() - t0) * 1e3
+        group.barrier()
+        ms = group.max_over_ranks(dev_ms)
+        total = group.sum_over_ranks(len(streams))
+        if rank == 0:
+            print(json.dumps({"metric": "STUB " + metric_name(args.model, B, world), "value": round(total * args.steps / (ms / 1e3), 2),
+                              "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": round(ms / args.steps, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                              "dtype": "none", "data": "stub", "config": {"workload": "launcher self-test, no device work", "streams": int(total)}}))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     import wrk
-    from wrk import replicas
-    group = replicas.ReplicaGroup(dist, device="cuda" if dist is not None else None)
     t0 = time.time()
-    gg = make_model_gguf(args.model, seed=42 + rank, mixed=args.mixed) if args.model not in CONFIGS_V6 else make_model_gguf(args.model, seed=42 + rank)
+    # every rank builds the SAME weights (a replica): seed 42
+    gg = make_model_gguf(args.model, seed=42, mixed=args.mixed) if args.model not in CONFIGS_V6 else make_model_gguf(args.model, seed=42)
     ctx = wrk.Context(local_rank)
     reader = wrk.GgufReader(gg)
     quant = {}
@@ -285,10 +370,9 @@ def main():
         lo, hi = (rng_.split("-") + [rng_])[:2]
         for l in range(int(lo), int(hi) + 1):
             quant[l] = {"int8": wrk.QUANT_INT8, "nf4": wrk.QUANT_NF4}[kind]
-    runtime = wrk.Runtime(ctx, reader, num_batch=args.batch, weights=wrk.WEIGHTS_INLINE, quant=quant or None)
+    runtime = wrk.Runtime(ctx, reader, num_batch=B, weights=wrk.WEIGHTS_INLINE, quant=quant or None)
     load_s = time.time() - t0
-    B = args.batch
-    first = [(17 + 101 * b) % (runtime.info.num_vocab - 1) for b in range(B)]
+    first = [(17 + 101 * g) % (runtime.info.num_vocab - 1) for g in streams]
     token_bytes = runtime.token_bytes(B)
 
     def barrier():
@@ -307,24 +391,28 @@ def main():
     wall_ms = (time.perf_counter() - w0) * 1e3
     barrier()
     ms = group.max_over_ranks(max(dev_ms, 0.0))
+    wall_ms = group.max_over_ranks(wall_ms)
 
     if rank == 0:
         ms_per_step = ms / args.steps
         value = world * B * args.steps / (ms / 1e3)
         achieved = token_bytes / (ms_per_step / 1e3) / 1e9
+        traffic, traffic_source = measured_traffic(args.model, B, args.mode)
         out = {
-            "metric": "tokens/sec RWKV-7 1.5B Q4_K_M decode @1 GPU; achieved HBM GB/s vs roofline",
+            "metric": metric_name(args.model, B, world),
             "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
             "config": {"workload": (f"RWKV-6 World {args.model[3:]} {'Q8_0' if args.model == 'v6-14B' else 'Q5_K_M (Q5_K matrices)'}, Q6_K head, F16 LoRA"
                                     f"{', quant map ' + args.quant if args.quant else ''}, batch={B} greedy decode, "
                                     if args.model in CONFIGS_V6 else
-                                    f"RWKV-7 World {args.model} Q4_K_M (Q4_K matrices, Q6_K head, F16 LoRA) batch={B} greedy decode, ") +
+                                    f"RWKV-7 World {args.model} Q4_K_M ({'llama.cpp mix: Q4_K + Q6_K attn/ffn value' if args.mixed else 'Q4_K matrices'}, Q6_K head, F16 LoRA) batch={B} greedy decode, ") +
                                    f"{'fused kernels' if args.mode == 1 else 'one kernel per reference op'} under hipGraph",
-                       "streams_per_gpu": B, "parallelism": f"replicas x{world}" if world > 1 else "single"},
+                       "streams_per_gpu": B, "streams": world * B, "parallelism": f"replicas x{world}" if world > 1 else "single"},
+            # per GPU: every replica streams its own copy of the weights
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.model, B, args.mode),
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                         "peak_measured": HBM_MEASURED_GBS, "frac_of_measured": round(achieved / HBM_MEASURED_GBS, 4),
                          "kernel": "one decode step = one hipGraph launch", "algorithmic_bytes_per_launch": token_bytes},
             "wall_ms_per_step_incl_host": round(wall_ms / args.steps, 5), "load_seconds": round(load_s, 1),
         }

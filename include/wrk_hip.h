@@ -275,6 +275,22 @@ int32_t wrk_v7_infer(wrk_ctx* ctx, wrk_v7_model* model, wrk_v7_state* state,
                      const uint32_t* tokens, const uint16_t* emb_rows, const uint32_t* cursors, uint32_t num_token,
                      const uint32_t* headers, uint32_t num_header, float* logits, uint32_t* argmax, uint32_t mode);
 
+/* Bundle::<F>::new (v7.rs:514-536; Runtime<F> v7.rs:281-364 is generic over the activation type): WRK_F16 = Bundle::<f16>, the
+ * reference's default build; WRK_F32 = Bundle::<f32>: every frame buffer but `input` holds f32, matmuls read f32 inputs
+ * (IN_FP32 shader variants), the op-by-op launch list runs whatever `mode` says.  Call between jobs; drops cached programs. */
+int32_t wrk_v7_model_set_frame_dtype(wrk_ctx* ctx, wrk_v7_model* model, uint32_t dtype);
+
+/* Parity instrumentation at the reference's own seam: v7::Hook / HookMap closures receive the `Frame` (state + Runtime<F>
+ * buffers) at every stage of a layer (v7.rs:386-421, 497-502) and examples/inspect.rs:100-248 reads each buffer back per layer.
+ *   wrk_v7_infer_layer: run ONLY `layer` of a job (mode as wrk_v7_infer) on a caller-supplied layer input x [D, num_token] and
+ *                       layer-0 value v_first [D, num_token] (NULL for layer 0), both in the frame dtype; the state slice of the layer advances
+ *   wrk_v7_frame_read : TensorGpu::back of one frame buffer, by inspect.rs's name (x, att_x, att_r, att_w, att_k, att_v, att_a, att_g,
+ *                       att_o, att_kk, att_vv, att_n, att_rx ... att_gx, aux_w/a/g/v, ffn_x, ffn_kx, ffn_k, ffn_v; att_x_ln = LN1(x) of the
+ *                       fused decode path); dst NULL returns the size.  In mode 1 only the buffers the fused kernels materialise are meaningful. */
+int32_t wrk_v7_infer_layer(wrk_ctx* ctx, wrk_v7_model* model, wrk_v7_state* state, uint32_t layer, const void* x, const void* v_first,
+                           const uint32_t* cursors, uint32_t num_token, uint32_t mode);
+int32_t wrk_v7_frame_read(wrk_ctx* ctx, wrk_v7_model* model, const char* name, uint32_t num_token, void* dst, size_t capacity, size_t* bytes);
+
 /* Greedy decode loop kept on the device (the reference's bench loop, examples/bench.rs:224-236,
  * with softmax+argmax moved on device): every sequence b feeds `first_tokens[b]`, then its own
  * argmax, for `steps` steps.  out_tokens: host u32 [steps, num_batch] or NULL.  One hipGraph per

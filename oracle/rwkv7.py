@@ -296,7 +296,8 @@ class V7Runtime:
 
         # embed (v7.rs:438-474, 649-659): CPU gather of f16 rows, LN(ln0) in place, blit to x
         inp = m.emb[tokens]
-        x = rnd(layer_norm(inp, m.ln0[0], m.ln0[1], LN_EPS))
+        # Runtime::input is TensorGpu<f16> whatever F is (v7.rs:283): LN(ln0) runs in place on it, then blit -> x (F)
+        x = rnd(r16(layer_norm(inp, m.ln0[0], m.ln0[1], LN_EPS)))
         self._tr("emb", "x", x)
         v0 = None
         for li, layer in enumerate(m.layers):
@@ -312,16 +313,22 @@ class V7Runtime:
             r = self._mm(p["w_r"], sx["r"])
             k = self._mm(p["w_k"], sx["k"])
             v = self._mm(p["w_v"], sx["v"])
+            self._tr(li, "k_raw", k); self._tr(li, "v_raw", v)
+            for n in "rwkvag":
+                self._tr(li, f"att_{n}x", sx[n])
             # 5
             aux_w = self._mm(p["w1"], sx["w"], "tanh")
+            self._tr(li, "aux_w", aux_w)
             w = self._mm(p["w2"], aux_w)
             w = rnd(p["w0"][None, :] + w)
             # 6
             aux_a = self._mm(p["a1"], sx["a"])
+            self._tr(li, "aux_a", aux_a)
             a = self._mm(p["a2"], aux_a)
             a = rnd(sigmoid(p["a0"][None, :] + a))
             # 7
             aux_g = self._mm(p["g1"], sx["g"], "sigmoid")
+            self._tr(li, "aux_g", aux_g)
             g = self._mm(p["g2"], aux_g)
             # 8
             kk = rnd(p["k_k"][None, :] * k)
@@ -333,8 +340,10 @@ class V7Runtime:
                 v0 = v.copy()
             else:
                 aux_v = self._mm(p["v1"], sx["v"])
+                self._tr(li, "aux_v", aux_v)
                 vv = self._mm(p["v2"], aux_v)
                 vv = rnd(sigmoid(p["v0"][None, :] + vv))
+                self._tr(li, "vv", vv)
                 v = rnd(mix(v, v0, vv))                                   # lerp REVERSED: y <- mix(y, x, f)
             self._tr(li, "r", r); self._tr(li, "w", w); self._tr(li, "k", k); self._tr(li, "v", v)
             self._tr(li, "a", a); self._tr(li, "g", g); self._tr(li, "kk", kk)
@@ -367,6 +376,7 @@ class V7Runtime:
             self._tr(li, "att_x", att_x)
             # 16
             o = self._mm(p["w_o"], att_x)
+            self._tr(li, "att_o", o)
             x = rnd(o + x)
             self._tr(li, "x_att", x)
             # 17
@@ -376,6 +386,7 @@ class V7Runtime:
             # 19-20
             fk = self._mm(p["ffn_w_k"], kx, "squared_relu")
             fv = self._mm(p["ffn_w_v"], fk)
+            self._tr(li, "ffn_x", ffn_x); self._tr(li, "ffn_kx", kx); self._tr(li, "ffn_k", fk); self._tr(li, "ffn_v", fv)
             # 21: channel_mix_v7 saves the ffn shift state of each sequence's last token
             for t in np.nonzero(lasts)[0]:
                 st[batches[t], S + 1, :] = ffn_x[t]

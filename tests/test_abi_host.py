@@ -86,6 +86,38 @@ def test_host_reader_rejects_bad_files():
         wrk.GgufReader(bytes(data[: len(data) // 2]))
 
 
+def _craft(tensors, pad=4096):
+    """Minimal GGUF v3 with a hand-written tensor table: (name, dims, type id, offset) and `pad` zero bytes of data."""
+    import struct
+
+    def wstr(s):
+        return struct.pack("<Q", len(s)) + s.encode()
+
+    head = bytearray(struct.pack("<IIQQ", 0x46554747, 3, len(tensors), 1))
+    head += wstr("general.architecture") + struct.pack("<I", 8) + wstr("rwkv7")
+    for nm, dims, tid, off in tensors:
+        head += wstr(nm) + struct.pack("<I", len(dims)) + b"".join(struct.pack("<Q", d) for d in dims) + struct.pack("<IQ", tid, off)
+    base = (len(head) + 31) & ~31
+    return bytes(head) + b"\0" * (base - len(head) + pad)
+
+
+def test_host_reader_overflow_and_truncation_cases():
+    """file-supplied dims / offsets are overflow-checked before any pointer is formed from them."""
+    ok = _craft([("blk.0.attn_norm.weight", [64], 0, 0)])
+    assert wrk.GgufReader(ok).shape("blocks.0.ln1.weight") == [64]
+    bad = [
+        _craft([("blk.0.attn_norm.weight", [64], 0, 2 ** 64 - 32)]),                    # offset wraps past the range check
+        _craft([("blk.0.attn_norm.weight", [64], 0, 2 ** 63)]),                         # plain out of range
+        _craft([("blk.0.attn_norm.weight", [2 ** 33, 2 ** 33], 0, 0)]),                 # element count overflows u64
+        _craft([("blk.0.attn_norm.weight", [2 ** 62], 0, 0)]),                          # byte count overflows u64
+        _craft([("blk.0.attn_norm.weight", [2048], 0, 0)], pad=4096),                   # 8 KiB of f32 in a 4 KiB data area
+        _craft([("blk.0.time_mix_lerp_fused.weight", [64, 1, 1, 5], 0, 0)]),            # fused lerp tensor with 5 slices, 6 are read
+    ]
+    for b in bad:
+        with pytest.raises(wrk.WrkError):
+            wrk.GgufReader(b)
+
+
 L, F, N = wrk.RNN_LAST, wrk.RNN_FULL, wrk.RNN_NONE
 
 

@@ -39,6 +39,8 @@ int32_t wrk_ctx_destroy(wrk_ctx* ctx) {
     hipStreamSynchronize(ctx->stream);
     hipStreamSynchronize(ctx->read_stream);
     if (ctx->staging) hipHostFree(ctx->staging);
+    for (auto& kv : ctx->sessions) { hipGraph_t g = nullptr; hipStreamEndCapture(kv.second, &g); if (g) hipGraphDestroy(g); hipStreamDestroy(kv.second); }
+    for (hipStream_t s : ctx->capture_pool) hipStreamDestroy(s);
     hipEventDestroy(ctx->read_event);
     hipStreamDestroy(ctx->read_stream);
     hipStreamDestroy(ctx->stream);
@@ -148,7 +150,7 @@ int32_t wrk_buf_copy(wrk_ctx* ctx, const wrk_buf* src, size_t so, wrk_buf* dst, 
     WRK_ARG(ctx, so + bytes <= src->bytes && dof + bytes <= dst->bytes, "wrk_buf_copy: out of range");
     if (bytes == 0) return WRK_OK;
     WRK_HIP(ctx, hipSetDevice(ctx->device));
-    WRK_HIP(ctx, hipMemcpyAsync((char*)dst->ptr + dof, (const char*)src->ptr + so, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    WRK_HIP(ctx, hipMemcpyAsync((char*)dst->ptr + dof, (const char*)src->ptr + so, bytes, hipMemcpyDeviceToDevice, ctx->op_stream()));     // an encoder command
     return WRK_OK;
 }
 
@@ -156,10 +158,16 @@ int32_t wrk_buf_copy(wrk_ctx* ctx, const wrk_buf* src, size_t so, wrk_buf* dst, 
 int32_t wrk_capture_begin(wrk_ctx* ctx) {
     if (!ctx) return WRK_E_ARG;
     LOCK(ctx);
-    WRK_ARG(ctx, !ctx->capturing, "capture already in progress");
+    WRK_ARG(ctx, !ctx->capturing_here(), "this thread already has a capture in progress on the context");
     WRK_HIP(ctx, hipSetDevice(ctx->device));
-    WRK_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-    ctx->capturing = true;
+    hipStream_t s = nullptr;
+    if (!ctx->capture_pool.empty()) { s = ctx->capture_pool.back(); ctx->capture_pool.pop_back(); }
+    else WRK_HIP(ctx, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    // thread-local mode: only THIS thread is restricted while its capture is open; other threads allocate, upload,
+    // launch and read as usual
+    const hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) { ctx->capture_pool.push_back(s); return wrk_fail(ctx, WRK_E_HIP, "hipStreamBeginCapture: %s", hipGetErrorString(e)); }
+    ctx->sessions[std::this_thread::get_id()] = s;
     return WRK_OK;
 }
 
@@ -167,10 +175,13 @@ int32_t wrk_capture_end(wrk_ctx* ctx, wrk_program** out) {
     if (!ctx || !out) return WRK_E_ARG;
     LOCK(ctx);
     *out = nullptr;
-    WRK_ARG(ctx, ctx->capturing, "no capture in progress");
-    ctx->capturing = false;
+    auto it = ctx->sessions.find(std::this_thread::get_id());
+    WRK_ARG(ctx, it != ctx->sessions.end(), "no capture in progress on this thread");
+    hipStream_t s = it->second;
+    ctx->sessions.erase(it);
+    ctx->capture_pool.push_back(s);
     hipGraph_t g = nullptr;
-    WRK_HIP(ctx, hipStreamEndCapture(ctx->stream, &g));
+    WRK_HIP(ctx, hipStreamEndCapture(s, &g));
     hipGraphExec_t e = nullptr;
     hipError_t err = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
     if (err != hipSuccess) { hipGraphDestroy(g); return wrk_fail(ctx, WRK_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(err)); }
@@ -403,8 +414,8 @@ int32_t wrk_op_matmul(wrk_ctx* ctx, const wrk_matrix* mat, const wrk_tensor* inp
     j.scale = mat->out_scale;
     int rc = -2;
     const size_t ntok = (size_t)input->view.shape[1] * input->view.shape[2];
-    if (turbo && ntok >= 2) rc = wrk::matmul_mfma(ctx->stream, j, ctx->num_cu);     // tiles are padded to 16 tokens
-    if (rc == -2) rc = wrk::matvec(ctx->stream, &j, 1, ctx->num_cu);
+    if (turbo && ntok >= 2) rc = wrk::matmul_mfma(ctx->op_stream(), j, ctx->num_cu);     // tiles are padded to 16 tokens
+    if (rc == -2) rc = wrk::matvec(ctx->op_stream(), &j, 1, ctx->num_cu);
     WRK_ARG(ctx, rc == 0, "matmul: launch configuration rejected");
     WRK_LAUNCH_CHECK(ctx);
     return WRK_OK;
@@ -414,7 +425,7 @@ int32_t wrk_op_layer_norm(wrk_ctx* ctx, const wrk_buf* w, const wrk_buf* b, cons
     ENTER(ctx);
     CHECK_T(x, "layer_norm x");
     WRK_ARG(ctx, w && b && w->bytes >= (size_t)x->view.shape[0] * 2 && b->bytes >= (size_t)x->view.shape[0] * 2, "layer_norm: w/b must hold C f16");
-    wrk::layer_norm(ctx->stream, w->ptr, b->ptr, make_dtensor(x), eps);
+    wrk::layer_norm(ctx->op_stream(), w->ptr, b->ptr, make_dtensor(x), eps);
     WRK_LAUNCH_CHECK(ctx);
     return WRK_OK;
 }
@@ -425,7 +436,7 @@ int32_t wrk_op_group_norm(wrk_ctx* ctx, const wrk_buf* w, const wrk_buf* b, cons
     const size_t need = (size_t)x->view.shape[0] * x->view.shape[1] * 2;
     WRK_ARG(ctx, w && b && w->bytes >= need && b->bytes >= need, "group_norm: w/b must hold S*H f16");
     WRK_ARG(ctx, x->view.shape[0] <= 64 * 1024, "group_norm: head size too large");
-    wrk::group_norm(ctx->stream, w->ptr, b->ptr, make_dtensor(x), eps);
+    wrk::group_norm(ctx->op_stream(), w->ptr, b->ptr, make_dtensor(x), eps);
     WRK_LAUNCH_CHECK(ctx);
     return WRK_OK;
 }
@@ -433,7 +444,7 @@ int32_t wrk_op_group_norm(wrk_ctx* ctx, const wrk_buf* w, const wrk_buf* b, cons
 int32_t wrk_op_l2_norm(wrk_ctx* ctx, const wrk_tensor* x, float eps) {
     ENTER(ctx);
     CHECK_T(x, "l2_norm x");
-    wrk::l2_norm(ctx->stream, make_dtensor(x), eps);
+    wrk::l2_norm(ctx->op_stream(), make_dtensor(x), eps);
     WRK_LAUNCH_CHECK(ctx);
     return WRK_OK;
 }
@@ -451,7 +462,7 @@ int32_t wrk_op_token_shift(wrk_ctx* ctx, const wrk_buf* cursors, const wrk_tenso
                      time_mix->view.shape[2] == output->view.shape[2], "token_shift: time_mix must be [C, 1 or T, I] with I = output.shape[2]");
     WRK_ARG(ctx, state->view.shape[0] == input->view.shape[0] && state->view.shape[1] == 1, "token_shift: state must be [C, 1, B]");
     WRK_ARG(ctx, cursors && cursors->bytes >= (size_t)input->view.shape[1] * 4, "token_shift: cursors must hold T u32");
-    wrk::token_shift(ctx->stream, (const uint32_t*)cursors->ptr, make_dtensor(time_mix), make_dtensor(state), make_dtensor(input), make_dtensor(output), reversed);
+    wrk::token_shift(ctx->op_stream(), (const uint32_t*)cursors->ptr, make_dtensor(time_mix), make_dtensor(state), make_dtensor(input), make_dtensor(output), reversed);
     WRK_LAUNCH_CHECK(ctx);
     return WRK_OK;
 }
@@ -462,7 +473,7 @@ int32_t wrk_op_transpose(wrk_ctx* ctx, const wrk_tensor* input, const wrk_tensor
     CHECK_T(output, "transpose output");
     WRK_ARG(ctx, input->view.shape[0] == output->view.shape[0] && input->view.shape[1] == output->view.shape[2] && input->view.shape[2] == output->view.shape[1],
             "transpose: output must be [C, B, T] for input [C, T, B]");
-    wrk::transpose(ctx->stream, make_dtensor(input), make_dtensor(output));
+    wrk::transpose(ctx->op_stream(), make_dtensor(input), make_dtensor(output));
     WRK_LAUNCH_CHECK(ctx);
     return WRK_OK;
 }
@@ -482,7 +493,7 @@ int32_t wrk_op_time_mix_v6(wrk_ctx* ctx, const wrk_buf* cursors, const wrk_tenso
     WRK_ARG(ctx, state->view.shape[0] == S * H && state->view.shape[1] == S + 1 && state->dtype == WRK_F32, "time_mix_v6: state must be f32 [C, S+1, B]");
     WRK_ARG(ctx, time_first && time_first->bytes >= (size_t)S * H * 4, "time_mix_v6: time_first must hold S*H f32");
     WRK_ARG(ctx, cursors && cursors->bytes >= (size_t)T * 4, "time_mix_v6: cursors must hold T u32");
-    wrk::time_mix_v6(ctx->stream, (const uint32_t*)cursors->ptr, make_dtensor(time_decay), time_first->ptr, make_dtensor(state), make_dtensor(k),
+    wrk::time_mix_v6(ctx->op_stream(), (const uint32_t*)cursors->ptr, make_dtensor(time_decay), time_first->ptr, make_dtensor(state), make_dtensor(k),
                      make_dtensor(v), make_dtensor(r), make_dtensor(x));
     WRK_LAUNCH_CHECK(ctx);
     return WRK_OK;
@@ -497,7 +508,7 @@ int32_t wrk_op_channel_mix(wrk_ctx* ctx, const wrk_buf* cursors, const wrk_tenso
     WRK_ARG(ctx, SAME_SHAPE(v, x) && SAME_SHAPE(r, x), "channel_mix: r/v/x shape mismatch");
     WRK_ARG(ctx, state->view.shape[0] == x->view.shape[0] && state->view.shape[1] == 1, "channel_mix: state must be [C, 1, B]");
     WRK_ARG(ctx, cursors && cursors->bytes >= (size_t)x->view.shape[1] * 4, "channel_mix: cursors must hold T u32");
-    wrk::channel_mix_v6(ctx->stream, (const uint32_t*)cursors->ptr, make_dtensor(state), make_dtensor(r), make_dtensor(v), make_dtensor(x));
+    wrk::channel_mix_v6(ctx->op_stream(), (const uint32_t*)cursors->ptr, make_dtensor(state), make_dtensor(r), make_dtensor(v), make_dtensor(x));
     WRK_LAUNCH_CHECK(ctx);
     return WRK_OK;
 }
@@ -509,7 +520,7 @@ static int32_t binary_op(wrk_ctx* ctx, int is_mul, const wrk_tensor* input, cons
     WRK_ARG(ctx, input->view.shape[0] == output->view.shape[0], "binary: channel mismatch");
     WRK_ARG(ctx, input->view.shape[1] == 1 || input->view.shape[1] == output->view.shape[1], "binary: token extent must be 1 or equal");
     WRK_ARG(ctx, input->view.shape[2] == 1 || input->view.shape[2] == output->view.shape[2], "binary: batch extent must be 1 or equal");
-    wrk::binary(ctx->stream, is_mul, make_dtensor(input), make_dtensor(output), ax, ay, ao);
+    wrk::binary(ctx->op_stream(), is_mul, make_dtensor(input), make_dtensor(output), ax, ay, ao);
     WRK_LAUNCH_CHECK(ctx);
     return WRK_OK;
 }
@@ -523,7 +534,7 @@ int32_t wrk_op_lerp(wrk_ctx* ctx, const wrk_tensor* x, const wrk_tensor* y, cons
     CHECK_T(f, "lerp f");
     WRK_ARG(ctx, SAME_SHAPE(x, y), "lerp: x/y shape mismatch");
     WRK_ARG(ctx, f->view.shape[0] == y->view.shape[0], "lerp: factor channel mismatch");
-    wrk::lerp(ctx->stream, make_dtensor(x), make_dtensor(y), make_dtensor(f), reversed);
+    wrk::lerp(ctx->op_stream(), make_dtensor(x), make_dtensor(y), make_dtensor(f), reversed);
     WRK_LAUNCH_CHECK(ctx);
     return WRK_OK;
 }
@@ -533,7 +544,7 @@ int32_t wrk_op_blit(wrk_ctx* ctx, const wrk_tensor* input, const wrk_tensor* out
     CHECK_T(input, "blit input");
     CHECK_T(output, "blit output");
     WRK_ARG(ctx, SAME_SHAPE(input, output), "blit: shape mismatch");
-    wrk::blit(ctx->stream, make_dtensor(input), make_dtensor(output));
+    wrk::blit(ctx->op_stream(), make_dtensor(input), make_dtensor(output));
     WRK_LAUNCH_CHECK(ctx);
     return WRK_OK;
 }
@@ -541,7 +552,7 @@ int32_t wrk_op_blit(wrk_ctx* ctx, const wrk_tensor* input, const wrk_tensor* out
 int32_t wrk_op_affine(wrk_ctx* ctx, const wrk_tensor* x, float scale, float bias) {
     ENTER(ctx);
     CHECK_T(x, "affine x");
-    wrk::affine(ctx->stream, make_dtensor(x), scale, bias);
+    wrk::affine(ctx->op_stream(), make_dtensor(x), scale, bias);
     WRK_LAUNCH_CHECK(ctx);
     return WRK_OK;
 }
@@ -549,7 +560,7 @@ int32_t wrk_op_affine(wrk_ctx* ctx, const wrk_tensor* x, float scale, float bias
 int32_t wrk_op_activate(wrk_ctx* ctx, const wrk_tensor* x, uint32_t act) {
     ENTER(ctx);
     CHECK_T(x, "activate x");
-    wrk::activate(ctx->stream, make_dtensor(x), act);
+    wrk::activate(ctx->op_stream(), make_dtensor(x), act);
     WRK_LAUNCH_CHECK(ctx);
     return WRK_OK;
 }
@@ -560,7 +571,7 @@ int32_t wrk_op_control_k_v7(wrk_ctx* ctx, const wrk_buf* p, const wrk_tensor* a,
     CHECK_T(k, "control_k k");
     WRK_ARG(ctx, SAME_SHAPE(a, k), "control_k: a/k shape mismatch");
     WRK_ARG(ctx, p && p->bytes >= (size_t)k->view.shape[0] * 2, "control_k: p must hold C f16");
-    wrk::control_k_v7(ctx->stream, p->ptr, make_dtensor(a), make_dtensor(k));
+    wrk::control_k_v7(ctx->op_stream(), p->ptr, make_dtensor(a), make_dtensor(k));
     WRK_LAUNCH_CHECK(ctx);
     return WRK_OK;
 }
@@ -580,7 +591,7 @@ int32_t wrk_op_time_mix_v7(wrk_ctx* ctx, const wrk_buf* cursors, const wrk_tenso
     WRK_ARG(ctx, state->view.shape[0] == S * H && state->view.shape[1] == S + 1, "time_mix_v7: state must be [C, S+1, B]");
     WRK_ARG(ctx, state->dtype == WRK_F32, "time_mix_v7: state must be f32");
     WRK_ARG(ctx, cursors && cursors->bytes >= (size_t)T * 4, "time_mix_v7: cursors must hold T u32");
-    wrk::time_mix_v7(ctx->stream, (const uint32_t*)cursors->ptr, make_dtensor(state), make_dtensor(r), make_dtensor(w), make_dtensor(n), make_dtensor(x));
+    wrk::time_mix_v7(ctx->op_stream(), (const uint32_t*)cursors->ptr, make_dtensor(state), make_dtensor(r), make_dtensor(w), make_dtensor(n), make_dtensor(x));
     WRK_LAUNCH_CHECK(ctx);
     return WRK_OK;
 }
@@ -593,7 +604,7 @@ int32_t wrk_op_time_first_v7(wrk_ctx* ctx, const wrk_buf* u, const wrk_tensor* r
     WRK_ARG(ctx, r->view.shape[0] == 64, "time_first_v7: head size must be 64");
     WRK_ARG(ctx, SAME_SHAPE(r, x), "time_first_v7: r/x shape mismatch");
     WRK_ARG(ctx, u && u->bytes >= (size_t)r->view.shape[0] * r->view.shape[1] * 2, "time_first_v7: u must hold S*H f16");
-    wrk::time_first_v7(ctx->stream, u->ptr, make_dtensor(r), make_dtensor(n), make_dtensor(x));
+    wrk::time_first_v7(ctx->op_stream(), u->ptr, make_dtensor(r), make_dtensor(n), make_dtensor(x));
     WRK_LAUNCH_CHECK(ctx);
     return WRK_OK;
 }
@@ -606,7 +617,7 @@ int32_t wrk_op_channel_mix_v7(wrk_ctx* ctx, const wrk_buf* cursors, const wrk_te
     WRK_ARG(ctx, SAME_SHAPE(v, x), "channel_mix: v/x shape mismatch");
     WRK_ARG(ctx, state->view.shape[0] == x->view.shape[0] && state->view.shape[1] == 1, "channel_mix: state must be [C, 1, B]");
     WRK_ARG(ctx, cursors && cursors->bytes >= (size_t)x->view.shape[1] * 4, "channel_mix: cursors must hold T u32");
-    wrk::channel_mix_v7(ctx->stream, (const uint32_t*)cursors->ptr, make_dtensor(state), make_dtensor(v), make_dtensor(x));
+    wrk::channel_mix_v7(ctx->op_stream(), (const uint32_t*)cursors->ptr, make_dtensor(state), make_dtensor(v), make_dtensor(x));
     WRK_LAUNCH_CHECK(ctx);
     return WRK_OK;
 }
@@ -614,7 +625,7 @@ int32_t wrk_op_channel_mix_v7(wrk_ctx* ctx, const wrk_buf* cursors, const wrk_te
 int32_t wrk_op_softmax(wrk_ctx* ctx, const wrk_tensor* x) {
     ENTER(ctx);
     CHECK_T(x, "softmax x");
-    wrk::softmax(ctx->stream, make_dtensor(x));
+    wrk::softmax(ctx->op_stream(), make_dtensor(x));
     WRK_LAUNCH_CHECK(ctx);
     return WRK_OK;
 }

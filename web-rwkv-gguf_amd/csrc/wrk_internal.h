@@ -9,6 +9,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "wrk_hip.h"
@@ -20,7 +21,18 @@ struct wrk_ctx {
     hipEvent_t read_event = nullptr;
     std::recursive_mutex mu;
     std::string err;
-    bool capturing = false;
+    // Context::encode (ops.rs:79-143) runs on tokio `spawn_blocking` workers while the runtime task submits cached jobs
+    // (runtime/mod.rs:139-167).  So an open capture belongs to the ENCODING THREAD and records on a private stream of
+    // its own: the submission stream and the read-back stream are never in capture mode, any number of threads may
+    // encode at once, and submissions / reads / uploads from other threads proceed meanwhile.  (Guarded by `mu`.)
+    std::map<std::thread::id, hipStream_t> sessions;    // open captures
+    std::vector<hipStream_t> capture_pool;              // idle capture streams
+    // the stream a wrk_op_* call of THIS thread records on: its open capture, else the submission stream
+    hipStream_t op_stream() {
+        auto it = sessions.find(std::this_thread::get_id());
+        return it == sessions.end() ? stream : it->second;
+    }
+    bool capturing_here() { return sessions.count(std::this_thread::get_id()) != 0; }
     int num_cu = 256;
     void* staging = nullptr;            // pinned host staging for wrk_buf_write
     size_t staging_bytes = 0;

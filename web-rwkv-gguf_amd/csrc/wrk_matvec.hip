@@ -914,6 +914,86 @@ __global__ void __launch_bounds__(256) matvec_kernel(const MatvecParams P) {
     }
 }
 
+// ------------------------------------------------------------------ f32 activation frames (Bundle::<f32>)
+// The reference's runtime is generic over the activation type F (v7.rs:281-320, `Runtime<F>`); with F = f32 its matmul
+// shaders read f32 inputs (IN_FP32) and multiply them with the decoded weight in f32.  This is that arithmetic: the weight
+// is decoded exactly as gguf.rs does (scale * (code - off) - min, each product / difference rounded once; rounded to f16 first
+// under WRK_MATRIX_ROUND_F16) and accumulated with fma in f32.  A correctness path (parity tests without f16 stores), not a
+// tuned one: one wave per row, inputs re-read from L2 per row.
+template <int KIND>
+__device__ __forceinline__ float row_dot_f32(const JobDev& J, const uint8_t* __restrict__ row, uint32_t r, size_t xbase, uint32_t lane) {
+    const uint32_t K = J.k, kpad = (K + 15u) & ~15u;
+    const uint32_t nch = num_chunks<KIND>(K, kpad);
+    const bool r16w = (J.flags & WRK_MATRIX_ROUND_F16) != 0;
+    const uint32_t phase = KIND == WRK_MAT_INT8 ? (uint32_t)((((size_t)r * K) >> 4) & 7u) : 0u;
+    float acc = 0.0f;
+    for (uint32_t c = lane; c < nch; c += 64) {
+        const Raw raw = load_raw<KIND>(row, K, c, phase);
+        if (KIND == WRK_MAT_F16) {
+            const f16x8 wv = __builtin_bit_cast(f16x8, raw.w);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (c * 8 + e < K) acc = __builtin_fmaf((float)wv[e], dt_load(J.in, xbase + c * 8 + e), acc);
+        } else if (KIND == WRK_MAT_NF4) {
+            const float amax = f16bits_to_f32(raw.a.x);
+            const uint32_t wd[4] = {raw.w.x, raw.w.y, raw.w.z, raw.w.w};
+#pragma unroll
+            for (int wi = 0; wi < 4; ++wi)
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    acc = __builtin_fmaf(J.aux[(wd[wi] >> (4 * i)) & 15u] * amax, dt_load(J.in, xbase + c * 32 + wi * 8 + i), acc);
+        } else {
+            Group lo, hi;
+            decode_raw<KIND>(raw, c, lo, hi);
+            const bool two = KIND != WRK_MAT_Q8_0 && KIND != WRK_MAT_INT8;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                if (g == 1 && !two) break;
+                const Group& G = g ? hi : lo;
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        float w = ((float)G.q[i][h] * G.qmul - G.off) * G.scale - G.minv;
+                        if (r16w) w = r16(w);
+                        acc = __builtin_fmaf(w, dt_load(J.in, xbase + G.xoff + 2 * i + h), acc);
+                    }
+            }
+        }
+    }
+    return wave_sum(acc);
+}
+
+__global__ void __launch_bounds__(256) matvec_f32in_kernel(const MatvecParams P) {
+    int ji = 0;
+#pragma unroll
+    for (int q = 1; q < MAX_JOBS; ++q)
+        if (q < P.njobs && blockIdx.x >= P.jobs[q].wg_begin) ji = q;
+    const JobDev& J = P.jobs[ji];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t r0 = (blockIdx.x - J.wg_begin) * J.rows_per_wg, r1 = min(r0 + J.rows_per_wg, J.m);
+    const uint32_t tk = blockIdx.y, t = tk % J.in.shape[1], b = tk / J.in.shape[1];
+    const size_t xbase = dt_index(J.in, 0, t, b);
+    for (uint32_t r = r0 + wave; r < r1; r += 4) {
+        const uint8_t* row = J.w + (size_t)r * J.row_bytes;
+        float v;
+        switch (J.kind) {
+            case WRK_MAT_Q4_K: v = row_dot_f32<WRK_MAT_Q4_K>(J, row, r, xbase, lane); break;
+            case WRK_MAT_Q5_K: v = row_dot_f32<WRK_MAT_Q5_K>(J, row, r, xbase, lane); break;
+            case WRK_MAT_Q6_K: v = row_dot_f32<WRK_MAT_Q6_K>(J, row, r, xbase, lane); break;
+            case WRK_MAT_Q8_0: v = row_dot_f32<WRK_MAT_Q8_0>(J, row, r, xbase, lane); break;
+            case WRK_MAT_INT8: v = row_dot_f32<WRK_MAT_INT8>(J, row, r, xbase, lane); break;
+            case WRK_MAT_NF4: v = row_dot_f32<WRK_MAT_NF4>(J, row, r, xbase, lane); break;
+            default: v = row_dot_f32<WRK_MAT_F16>(J, row, r, xbase, lane); break;
+        }
+        if (lane == 0) {
+            float o = act_apply(J.act, v * J.scale);
+            if (J.has_res) o = dt_round(J.out, o) + dt_load(J.res, dt_index(J.res, r, t, b));
+            dt_store(J.out, dt_index(J.out, r, t, b), o);
+        }
+    }
+}
+
 typedef void (*matvec_fn)(const MatvecParams);
 
 template <int NB, int KA, int KB>
@@ -1093,6 +1173,15 @@ int matvec(hipStream_t s, const MatJob* jobs, int njobs, int num_cu, bool dry_ru
         d.mixw = (const f16*)jobs[j].mixw; d.prev = jobs[j].prev; d.ln_out = (f16*)jobs[j].ln_out;
         d.carry_src = (const f16*)jobs[j].carry_src; d.carry_dst = jobs[j].carry_dst; d.gate = (const f16*)jobs[j].gate; d.scale = jobs[j].scale; d.dbg = jobs[j].dbg;
         wg += (jobs[j].m + d.rows_per_wg - 1) / d.rows_per_wg;
+    }
+    bool f32in = false;
+    for (int j = 0; j < njobs; ++j) f32in = f32in || jobs[j].in.dtype == WRK_F32;
+    if (f32in) {    // Bundle::<f32> frames: the f32-input kernel (no fused prologue / carry / arg-max there)
+        for (int j = 0; j < njobs; ++j)
+            if (jobs[j].pro || jobs[j].carry_dst || jobs[j].gate || jobs[j].amax_val) return -3;
+        if (dry_run) return 0;
+        hipLaunchKernelGGL(matvec_f32in_kernel, dim3(wg, ntok), dim3(256), 0, s, P);
+        return 0;
     }
     const uint32_t kpad = (kmax + 15u) & ~15u;
     // pick inputs-per-pass: LDS budget 144 KiB

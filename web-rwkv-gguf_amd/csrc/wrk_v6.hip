@@ -38,7 +38,7 @@ static inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 int32_t wrk_v6_model::ensure_scratch(uint32_t T, uint32_t NH) {
     if (T <= scratch_tokens && NH <= scratch_headers && scratch) return WRK_OK;
-    if (ctx->capturing) return wrk_fail(ctx, WRK_E_ARG, "scratch must be sized before capture");
+    if (ctx->capturing_here()) return wrk_fail(ctx, WRK_E_ARG, "scratch must be sized before capture");
     const uint32_t nt = T > scratch_tokens ? T : scratch_tokens, nh = NH > scratch_headers ? NH : scratch_headers;
     WRK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     drop_graphs();
@@ -83,8 +83,8 @@ static int32_t mm6(wrk_ctx* ctx, const wrk_matrix* m, DTensor in, DTensor out, u
     wrk::MatJob j{m->data, m->aux, m->kind, m->flags, m->k, m->m, (uint32_t)m->row_bytes, in, out, act, 0};
     j.scale = m->out_scale;
     int rc = -2;
-    if (in.shape[1] * in.shape[2] >= wrk::gemm_min_tokens()) rc = wrk::matmul_mfma(ctx->stream, j, ctx->num_cu);
-    if (rc == -2) rc = wrk::matvec(ctx->stream, &j, 1, ctx->num_cu);
+    if (in.shape[1] * in.shape[2] >= wrk::gemm_min_tokens()) rc = wrk::matmul_mfma(ctx->op_stream(), j, ctx->num_cu);
+    if (rc == -2) rc = wrk::matvec(ctx->op_stream(), &j, 1, ctx->num_cu);
     if (rc != 0) return wrk_fail(ctx, WRK_E_ARG, "matmul launch rejected (K=%u M=%u rc=%d)", m->k, m->m, rc);
     return WRK_OK;
 }
@@ -97,11 +97,11 @@ static wrk::MatJob job6m(const wrk_matrix* m, DTensor in, DTensor out, uint32_t 
 // several matrices x the same token count in one MFMA launch per kernel family; per-matrix launches when the GEMM declines
 static int32_t mm6_group(wrk_ctx* ctx, wrk::MatJob* jobs, int n) {
     const uint32_t T = jobs[0].in.shape[1] * jobs[0].in.shape[2];
-    if (T >= wrk::gemm_min_tokens() && wrk::matmul_mfma_multi(ctx->stream, jobs, n, ctx->num_cu) == 0) return WRK_OK;
+    if (T >= wrk::gemm_min_tokens() && wrk::matmul_mfma_multi(ctx->op_stream(), jobs, n, ctx->num_cu) == 0) return WRK_OK;
     for (int i = 0; i < n; ++i) {
         int rc = -2;
-        if (T >= wrk::gemm_min_tokens()) rc = wrk::matmul_mfma(ctx->stream, jobs[i], ctx->num_cu);
-        if (rc == -2) rc = wrk::matvec(ctx->stream, &jobs[i], 1, ctx->num_cu);
+        if (T >= wrk::gemm_min_tokens()) rc = wrk::matmul_mfma(ctx->op_stream(), jobs[i], ctx->num_cu);
+        if (rc == -2) rc = wrk::matvec(ctx->op_stream(), &jobs[i], 1, ctx->num_cu);
         if (rc != 0) return wrk_fail(ctx, WRK_E_ARG, "matmul launch rejected (K=%u M=%u rc=%d)", jobs[i].k, jobs[i].m, rc);
     }
     return WRK_OK;
@@ -109,7 +109,7 @@ static int32_t mm6_group(wrk_ctx* ctx, wrk::MatJob* jobs, int n) {
 #define MMG(jobs, n) do { int32_t _r = mm6_group(ctx, jobs, n); if (_r != WRK_OK) return _r; } while (0)
 
 int32_t wrk_v6_model::enqueue_ops(wrk_v7_state* st, uint32_t T, uint32_t NH, bool identity, bool merged) {
-    hipStream_t q = ctx->stream;
+    hipStream_t q = ctx->op_stream();
     const uint32_t D = d.num_emb, F = d.num_hidden, H = d.num_head, S = D / H, V = d.num_vocab, R = d.time_mix, W = d.time_decay;
     auto vec = [&](void* p, uint32_t c = 0, uint32_t dt = WRK_F16) { return make_dense(p, dt, c ? c : D, T); };
     auto heads = [&](void* p, uint32_t dt = WRK_F16) { return make_dense(p, dt, S, H, T); };
@@ -376,7 +376,7 @@ static wrk::MatJob job6(const wrk_matrix* m, DTensor in, DTensor out, uint32_t a
 // One decode step for T stacked tokens, each its own sequence.  Returns WRK_E_UNSUPPORTED (without launching anything)
 // when the model's shapes are outside the fused kernels' range; callers then use enqueue_ops.
 int32_t wrk_v6_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_t NH, bool identity, uint32_t batch0) {
-    hipStream_t q = ctx->stream;
+    hipStream_t q = ctx->op_stream();
     const uint32_t D = d.num_emb, F = d.num_hidden, H = d.num_head, S = 64, V = d.num_vocab, R = d.time_mix, W = d.time_decay;
     if (R > 128 || W > 128 || (R & 7u) || (W & 7u) || (D & 7u) || D > 8192) return WRK_E_UNSUPPORTED;
     for (auto& L : layers) {
@@ -635,7 +635,7 @@ int32_t wrk_v6_infer(wrk_ctx* ctx, wrk_v6_model* m, wrk_v7_state* st, const uint
     if (tokens) {
         rc = wrk_buf_write_raw(ctx, m->s.tokens, tokens, (size_t)T * 4);
         if (rc != WRK_OK) return rc;
-        wrk::gather_rows_f16(ctx->stream, m->d.emb_f16->ptr, m->s.tokens, m->s.input, D, T);
+        wrk::gather_rows_f16(ctx->op_stream(), m->d.emb_f16->ptr, m->s.tokens, m->s.input, D, T);
     } else {
         rc = wrk_buf_write_raw(ctx, m->s.input, emb_rows, (size_t)T * D * 2);
         if (rc != WRK_OK) return rc;
@@ -644,8 +644,9 @@ int32_t wrk_v6_infer(wrk_ctx* ctx, wrk_v6_model* m, wrk_v7_state* st, const uint
     if (mode == 1 && one_token_each) rc = m->enqueue_fused_decode(st, T, NH, identity, cursors[0] & 0xff);
     if (rc == WRK_E_UNSUPPORTED) rc = m->enqueue_ops(st, T, NH, identity, mode == 1 && !one_token_each);
     if (rc != WRK_OK) return rc;
-    if (NH && argmax) wrk::argmax_rows(ctx->stream, m->s.head_o, V, V, NH, m->s.argmax);
+    if (NH && argmax) wrk::argmax_rows(ctx->op_stream(), m->s.head_o, V, V, NH, m->s.argmax);
     WRK_LAUNCH_CHECK(ctx);
+    if (ctx->capturing_here()) return WRK_OK;   // recorded into the caller's program: results exist after it has been launched
     if (NH && logits) WRK_HIP(ctx, hipMemcpyAsync(logits, m->s.head_o, (size_t)NH * V * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (NH && argmax) WRK_HIP(ctx, hipMemcpyAsync(argmax, m->s.argmax, (size_t)NH * 4, hipMemcpyDeviceToHost, ctx->stream));
     WRK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -677,13 +678,13 @@ int32_t wrk_v6_generate_greedy(wrk_ctx* ctx, wrk_v6_model* m, wrk_v7_state* st, 
     const char* ng = getenv("WRK_NO_GRAPH");
     const bool eager = ng && ng[0] == '1';
     auto enqueue_step = [&]() -> int32_t {
-        wrk::gather_rows_f16(ctx->stream, m->d.emb_f16->ptr, m->s.tokens, m->s.input, D, B);
+        wrk::gather_rows_f16(ctx->op_stream(), m->d.emb_f16->ptr, m->s.tokens, m->s.input, D, B);
         int32_t r = WRK_E_UNSUPPORTED;
         if (mode == 1) r = m->enqueue_fused_decode(st, B, B, true, 0);
         if (r == WRK_E_UNSUPPORTED) r = m->enqueue_ops(st, B, B, true);
         if (r != WRK_OK) return r;
-        wrk::argmax_rows(ctx->stream, m->s.head_o, V, V, B, m->s.argmax);
-        wrk::advance_tokens(ctx->stream, m->s.argmax, m->s.tokens, m->history, m->s.counter, B);
+        wrk::argmax_rows(ctx->op_stream(), m->s.head_o, V, V, B, m->s.argmax);
+        wrk::advance_tokens(ctx->op_stream(), m->s.argmax, m->s.tokens, m->history, m->s.counter, B);
         return WRK_OK;
     };
     wrk_program* prog = nullptr;

@@ -53,6 +53,14 @@ struct wrk_v7_model {
     uint32_t* amax_idx = nullptr;
     size_t amax_cap = 0;
 
+    // teacher-forced single-layer runs (wrk_v7_infer_layer): the layer range the op list covers and whether the embedding
+    // stage (LN(ln0) + blit) is part of it; the defaults are the whole model
+    uint32_t layer_begin = 0, layer_end = 0xffffffffu;
+    bool skip_embed = false;
+    // activation dtype of the frame: WRK_F16 = Bundle::<f16> (the reference's default), WRK_F32 = Bundle::<f32> (v7.rs:281-320
+    // is generic over F).  F32 frames always take the op-by-op path with the f32-input matvec.
+    uint32_t act_dtype = WRK_F16;
+
     int32_t ensure_scratch(uint32_t T, uint32_t NH);
     int32_t ensure_history(size_t n);
     void drop_graphs();

@@ -20,7 +20,7 @@ static wrk::MatJob mj(const wrk_matrix* m, DTensor in, DTensor out, uint32_t act
 // ------------------------------------------------------------------ scratch ("Runtime<f16>" + "Header<f16>")
 int32_t wrk_v7_model::ensure_scratch(uint32_t T, uint32_t NH) {
     if (T <= scratch_tokens && NH <= scratch_headers && scratch) return WRK_OK;
-    if (ctx->capturing) return wrk_fail(ctx, WRK_E_ARG, "scratch must be sized before capture");
+    if (ctx->capturing_here()) return wrk_fail(ctx, WRK_E_ARG, "scratch must be sized before capture");
     const uint32_t nt = T > scratch_tokens ? T : scratch_tokens;
     const uint32_t nh = NH > scratch_headers ? NH : scratch_headers;
     WRK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -30,15 +30,16 @@ int32_t wrk_v7_model::ensure_scratch(uint32_t T, uint32_t NH) {
     const size_t D = d.num_emb, F = d.num_hidden, V = d.num_vocab;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += up256(bytes); return o; };
-    const size_t vecT = D * nt * 2;
+    const size_t esz = act_dtype == WRK_F32 ? 4 : 2;        // Runtime<F>: every buffer but `input` holds F
+    const size_t vecT = D * nt * esz;
     size_t o_named[32];
     int ni = 0;
     for (int i = 0; i < 23; ++i) o_named[ni++] = take(vecT);          // input, x, att_x, att_v0, 6 shifted, r w k v a g o, kk, vv, ffn_x, ffn_kx, ffn_v, spare
     const size_t o_n = take(vecT * 4);
-    const size_t o_auxw = take((size_t)d.lora_w * nt * 2), o_auxa = take((size_t)d.lora_a * nt * 2);
-    const size_t o_auxg = take((size_t)d.lora_g * nt * 2), o_auxv = take((size_t)d.lora_v * nt * 2);
-    const size_t o_ffnk = take(F * nt * 2);
-    const size_t o_headx = take(D * nh * 2), o_heado = take(V * nh * 4);
+    const size_t o_auxw = take((size_t)d.lora_w * nt * esz), o_auxa = take((size_t)d.lora_a * nt * esz);
+    const size_t o_auxg = take((size_t)d.lora_g * nt * esz), o_auxv = take((size_t)d.lora_v * nt * esz);
+    const size_t o_ffnk = take(F * nt * esz);
+    const size_t o_headx = take(D * nh * esz), o_heado = take(V * nh * 4);
     const size_t o_cur = take((size_t)nt * 4), o_tok = take((size_t)nt * 4), o_hdr = take((size_t)nh * 4), o_arg = take((size_t)nh * 4);
     const size_t o_cnt = take(256);
     WRK_HIP(ctx, hipMalloc(&scratch, off));
@@ -83,19 +84,19 @@ static wrk::MatJob mj(const wrk_matrix* m, DTensor in, DTensor out, uint32_t act
 static int32_t mm(wrk_ctx* ctx, const wrk_matrix* m, DTensor in, DTensor out, uint32_t act) {
     wrk::MatJob j = mj(m, in, out, act);
     int rc = -2;
-    if (in.shape[1] * in.shape[2] >= wrk::gemm_min_tokens()) rc = wrk::matmul_mfma(ctx->stream, j, ctx->num_cu);
-    if (rc == -2) rc = wrk::matvec(ctx->stream, &j, 1, ctx->num_cu);
+    if (in.shape[1] * in.shape[2] >= wrk::gemm_min_tokens()) rc = wrk::matmul_mfma(ctx->op_stream(), j, ctx->num_cu);
+    if (rc == -2) rc = wrk::matvec(ctx->op_stream(), &j, 1, ctx->num_cu);
     if (rc != 0) return wrk_fail(ctx, WRK_E_ARG, "matmul launch rejected (K=%u M=%u)", m->k, m->m);
     return WRK_OK;
 }
 // several matrices x the same token count in one MFMA launch per kernel family; per-matrix launches when the GEMM declines
 static int32_t mm_group(wrk_ctx* ctx, wrk::MatJob* jobs, int n) {
     const uint32_t T = jobs[0].in.shape[1] * jobs[0].in.shape[2];
-    if (T >= wrk::gemm_min_tokens() && wrk::matmul_mfma_multi(ctx->stream, jobs, n, ctx->num_cu) == 0) return WRK_OK;
+    if (T >= wrk::gemm_min_tokens() && wrk::matmul_mfma_multi(ctx->op_stream(), jobs, n, ctx->num_cu) == 0) return WRK_OK;
     for (int i = 0; i < n; ++i) {
         int rc = -2;
-        if (T >= wrk::gemm_min_tokens()) rc = wrk::matmul_mfma(ctx->stream, jobs[i], ctx->num_cu);
-        if (rc == -2) rc = wrk::matvec(ctx->stream, &jobs[i], 1, ctx->num_cu);
+        if (T >= wrk::gemm_min_tokens()) rc = wrk::matmul_mfma(ctx->op_stream(), jobs[i], ctx->num_cu);
+        if (rc == -2) rc = wrk::matvec(ctx->op_stream(), &jobs[i], 1, ctx->num_cu);
         if (rc != 0) return wrk_fail(ctx, WRK_E_ARG, "matmul launch rejected (K=%u M=%u)", jobs[i].k, jobs[i].m);
     }
     return WRK_OK;
@@ -108,18 +109,20 @@ static int32_t mm_group(wrk_ctx* ctx, wrk::MatJob* jobs, int n) {
 
 // ------------------------------------------------------------------ mode 0: the reference op list
 int32_t wrk_v7_model::enqueue_ops(wrk_v7_state* st, uint32_t T, uint32_t NH, bool identity_headers, bool merged) {
-    hipStream_t q = ctx->stream;
+    hipStream_t q = ctx->op_stream();
     const uint32_t D = d.num_emb, F = d.num_hidden, H = d.num_head, S = D / H, V = d.num_vocab;
-    auto vec = [&](void* p, uint32_t c = 0) { return make_dense(p, WRK_F16, c ? c : D, T); };
-    auto heads = [&](void* p) { return make_dense(p, WRK_F16, S, H, T); };
+    const uint32_t AT = act_dtype;      // F of Runtime<F>
+    if (AT != WRK_F16) merged = false;  // the merged launches are written for dense f16 rows
+    auto vec = [&](void* p, uint32_t c = 0) { return make_dense(p, AT, c ? c : D, T); };
+    auto heads = [&](void* p) { return make_dense(p, AT, S, H, T); };
     DTensor x = vec(s.x), att_x = vec(s.att_x), v0 = vec(s.att_v0);
     DTensor rx = vec(s.rx), wx = vec(s.wx), kx = vec(s.kx), vx = vec(s.vx), ax = vec(s.ax), gx = vec(s.gx);
     DTensor r = vec(s.r), w = vec(s.w), k = vec(s.k), v = vec(s.v), a = vec(s.a), g = vec(s.g), o = vec(s.o);
     DTensor kk = vec(s.kk), vv = vec(s.vv);
     DTensor ffn_x = vec(s.ffn_x), ffn_kx = vec(s.ffn_kx), ffn_v = vec(s.ffn_v), ffn_k = vec(s.ffn_k, F);
     DTensor aux_w = vec(s.aux_w, d.lora_w), aux_a = vec(s.aux_a, d.lora_a), aux_g = vec(s.aux_g, d.lora_g), aux_v = vec(s.aux_v, d.lora_v);
-    DTensor n4 = make_dense(s.n, WRK_F16, S, H, T, 4);
-    auto nslice = [&](uint32_t i) { DTensor t = make_dense(s.n, WRK_F16, D, T, 4); t.shape[2] = 1; t.offset[2] = i; return t; };
+    DTensor n4 = make_dense(s.n, AT, S, H, T, 4);
+    auto nslice = [&](uint32_t i) { DTensor t = make_dense(s.n, AT, D, T, 4); t.shape[2] = 1; t.offset[2] = i; return t; };
     auto bvec = [&](const wrk_buf* b) { return make_dense(b->ptr, WRK_F16, D, 1, 1); };
     // WRK_MERGE_MASK (debug): 1 shifts in one pass, 2 grouped projections, 4 pre-WKV stage, 8 post-WKV stage, 16 W_o add in the epilogue,
     // 32 blit + layer_norm in one pass, 64 ffn.value's add in the epilogue
@@ -130,11 +133,13 @@ int32_t wrk_v7_model::enqueue_ops(wrk_v7_state* st, uint32_t T, uint32_t NH, boo
                m_res = merged && (mask & 16u), m_ln = merged && (mask & 32u), m_tail = merged && (mask & 64u);
 
     // embed: LN(ln0) in place on the gathered rows, blit to x (v7.rs:649-659)
-    DTensor input = vec(s.input);
-    wrk::layer_norm(q, ln0_w->ptr, ln0_b->ptr, input, LN_EPS);
-    wrk::blit(q, input, x);
+    if (!skip_embed) {
+        DTensor input = make_dense(s.input, WRK_F16, D, T);     // Runtime::input is f16 whatever F is (v7.rs:283)
+        wrk::layer_norm(q, ln0_w->ptr, ln0_b->ptr, input, LN_EPS);
+        wrk::blit(q, input, x);
+    }
 
-    for (uint32_t li = 0; li < d.num_layer; ++li) {
+    for (uint32_t li = layer_begin; li < d.num_layer && li < layer_end; ++li) {
         const wrk_v7_layer_desc& L = layers[li];
         // state views (v7.rs:198-208): att = rows 0..S, ffn = row S+1 of [D, S+2, B]
         DTensor st_att = make_dense(st->layer_ptr(li), WRK_F32, D, S + 2, st->num_batch);
@@ -248,8 +253,8 @@ int32_t wrk_v7_model::enqueue_ops(wrk_v7_state* st, uint32_t T, uint32_t NH, boo
     }
     // header (v7.rs:1009-1036): gather header rows, LN(ln_out), head matmul into f32 logits
     if (NH > 0) {
-        DTensor head_x = make_dense(s.head_x, WRK_F16, D, NH);
-        if (identity_headers) wrk::blit(q, make_dense(s.x, WRK_F16, D, NH), head_x);
+        DTensor head_x = make_dense(s.head_x, AT, D, NH);
+        if (identity_headers) wrk::blit(q, make_dense(s.x, AT, D, NH), head_x);
         else wrk::gather_rows_any(q, x, s.headers, head_x, NH);
         wrk::layer_norm(q, ln_out_w->ptr, ln_out_b->ptr, head_x, LN_EPS);
         MM(head, head_x, make_dense(s.head_o, WRK_F32, V, NH), WRK_ACT_NONE);
@@ -415,7 +420,7 @@ static int32_t state_d2d(wrk_ctx* ctx, const wrk_v7_state* st, uint32_t batch, c
     for (uint32_t l = 0; l < st->num_layer; ++l) {
         float* slot = st->layer_ptr(l) + batch * per;
         float* snap = (float*)buf->ptr + l * per;
-        WRK_HIP(ctx, hipMemcpyAsync(to_state ? slot : snap, to_state ? snap : slot, per * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        WRK_HIP(ctx, hipMemcpyAsync(to_state ? slot : snap, to_state ? snap : slot, per * 4, hipMemcpyDeviceToDevice, ctx->op_stream()));
     }
     return WRK_OK;
 }
@@ -462,11 +467,11 @@ int32_t wrk_v7_infer(wrk_ctx* ctx, wrk_v7_model* m, wrk_v7_state* st, const uint
     rc = wrk_buf_write_raw(ctx, m->s.cursors, cursors, (size_t)T * 4);
     if (rc != WRK_OK) return rc;
     if (NH) { rc = wrk_buf_write_raw(ctx, m->s.headers, headers, (size_t)NH * 4); if (rc != WRK_OK) return rc; }
-    const bool fused = (mode == 1 && one_token_each && nseq == T);
+    const bool fused = (mode == 1 && one_token_each && nseq == T && m->act_dtype == WRK_F16);
     if (tokens) {
         rc = wrk_buf_write_raw(ctx, m->s.tokens, tokens, (size_t)T * 4);
         if (rc != WRK_OK) return rc;
-        if (!fused) wrk::gather_rows_f16(ctx->stream, m->emb->ptr, m->s.tokens, m->s.input, D, T);
+        if (!fused) wrk::gather_rows_f16(ctx->op_stream(), m->emb->ptr, m->s.tokens, m->s.input, D, T);
     } else {
         rc = wrk_buf_write_raw(ctx, m->s.input, emb_rows, (size_t)T * D * 2);
         if (rc != WRK_OK) return rc;
@@ -479,15 +484,16 @@ int32_t wrk_v7_infer(wrk_ctx* ctx, wrk_v7_model* m, wrk_v7_state* st, const uint
         if (fused) r = m->enqueue_fused_decode(st, T, NH, identity, tokens != nullptr, NH && argmax, false, cursors[0] & 0xff);
         else {
             r = m->enqueue_ops(st, T, NH, identity, mode == 1);
-            if (r == WRK_OK && NH && argmax) wrk::argmax_rows(ctx->stream, m->s.head_o, V, V, NH, m->s.argmax);
+            if (r == WRK_OK && NH && argmax) wrk::argmax_rows(ctx->op_stream(), m->s.head_o, V, V, NH, m->s.argmax);
         }
         return r;
     };
     static const bool no_graph = [] { const char* e = getenv("WRK_NO_GRAPH"); return e && e[0] == '1'; }();
-    if (no_graph || ctx->capturing) rc = enqueue_job();
+    if (no_graph || ctx->capturing_here()) rc = enqueue_job();
     else {
-        const uint32_t flags = 16u | (fused ? 1u : 0u) | (identity ? 2u : 0u) | (tokens ? 4u : 0u) | ((NH && argmax) ? 8u : 0u) |
-                               (fused ? (cursors[0] & 0xffu) << 8 : 0u);
+        // bit 5: a non-fused job enqueues the merged launch list in mode 1 and the reference op list in mode 0 -- two graphs
+        const uint32_t flags = 16u | (m->act_dtype == WRK_F32 ? 64u : 0u) | (fused ? 1u : 0u) | (identity ? 2u : 0u) | (tokens ? 4u : 0u) | ((NH && argmax) ? 8u : 0u) |
+                               ((!fused && mode == 1) ? 32u : 0u) | (fused ? (cursors[0] & 0xffu) << 8 : 0u);
         const wrk_v7_model::GraphKey key{st->uid, T, flags, NH};
         wrk_program* prog = nullptr;
         auto it = m->graphs.find(key);
@@ -509,10 +515,97 @@ int32_t wrk_v7_infer(wrk_ctx* ctx, wrk_v7_model* m, wrk_v7_state* st, const uint
     }
     if (rc != WRK_OK) return rc;
     WRK_LAUNCH_CHECK(ctx);
+    if (ctx->capturing_here()) return WRK_OK;   // recorded into the caller's program: results exist after it has been launched
     if (NH && logits) WRK_HIP(ctx, hipMemcpyAsync(logits, m->s.head_o, (size_t)NH * V * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (NH && argmax) WRK_HIP(ctx, hipMemcpyAsync(argmax, m->s.argmax, (size_t)NH * 4, hipMemcpyDeviceToHost, ctx->stream));
     WRK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return WRK_OK;
+}
+
+// Bundle::<F>::new (v7.rs:514-536): the activation type of the frame.  F16 is the reference's default build
+// (`Bundle::<f16>`); F32 stores every Runtime<F> buffer in f32 and takes the op-by-op path with f32-input matmuls.
+int32_t wrk_v7_model_set_frame_dtype(wrk_ctx* ctx, wrk_v7_model* m, uint32_t dtype) {
+    if (!ctx || !m) return WRK_E_ARG;
+    LOCK(ctx);
+    WRK_ARG(ctx, dtype == WRK_F16 || dtype == WRK_F32, "frame dtype must be WRK_F16 or WRK_F32");
+    WRK_ARG(ctx, !ctx->capturing_here(), "cannot change the frame inside a capture");
+    if (dtype == m->act_dtype) return WRK_OK;
+    WRK_HIP(ctx, hipSetDevice(ctx->device));
+    WRK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    m->drop_graphs();
+    if (m->scratch) hipFree(m->scratch);
+    m->scratch = nullptr;
+    m->scratch_tokens = m->scratch_headers = 0;
+    m->act_dtype = dtype;
+    return WRK_OK;
+}
+
+// Teacher-forced run of ONE layer (parity tests; the reference reaches the same buffers through v7::HookMap closures over
+// `Frame`, v7.rs:386-421, examples/inspect.rs:100-248): the layer's op list (mode 0), or its fused / merged launches (mode 1),
+// on a caller-supplied layer input.  Every Runtime<F> buffer of the frame stays readable through wrk_v7_frame_read.
+int32_t wrk_v7_infer_layer(wrk_ctx* ctx, wrk_v7_model* m, wrk_v7_state* st, uint32_t layer, const void* x, const void* v_first,
+                           const uint32_t* cursors, uint32_t T, uint32_t mode) {
+    if (!ctx || !m || !st || !x || !cursors) return WRK_E_ARG;
+    LOCK(ctx);
+    WRK_HIP(ctx, hipSetDevice(ctx->device));
+    WRK_ARG(ctx, !ctx->capturing_here(), "wrk_v7_infer_layer cannot be captured");
+    WRK_ARG(ctx, layer < m->d.num_layer, "layer %u out of range", layer);
+    WRK_ARG(ctx, T >= 1, "no tokens");
+    WRK_ARG(ctx, layer == 0 || v_first, "layers above 0 read the layer-0 value (att_v0)");
+    WRK_ARG(ctx, st->num_emb == m->d.num_emb && st->num_layer == m->d.num_layer, "state does not belong to this model");
+    bool one_token_each = true;
+    uint32_t nseq = 0;
+    std::vector<uint8_t> seen(256, 0);
+    for (uint32_t t = 0; t < T; ++t) {
+        const uint32_t c = cursors[t], b = c & 0xff, tok = (c >> 8) & 0xffff, len = c >> 24;
+        WRK_ARG(ctx, b < st->num_batch, "cursor %u: batch %u >= %u", t, b, st->num_batch);
+        WRK_ARG(ctx, len >= 1 && tok <= t && t < tok + len && tok + len <= T, "cursor %u: bad range", t);
+        if (tok == t) { ++nseq; WRK_ARG(ctx, !seen[b], "cursor %u: batch %u twice", t, b); seen[b] = 1; }
+        if (len != 1) one_token_each = false;
+    }
+    int32_t rc = m->ensure_scratch(T, 1);
+    if (rc != WRK_OK) return rc;
+    const size_t esz = m->act_dtype == WRK_F32 ? 4 : 2;
+    rc = wrk_buf_write_raw(ctx, m->s.cursors, cursors, (size_t)T * 4);
+    if (rc == WRK_OK) rc = wrk_buf_write_raw(ctx, m->s.x, x, (size_t)T * m->d.num_emb * esz);
+    if (rc == WRK_OK && v_first) rc = wrk_buf_write_raw(ctx, m->s.att_v0, v_first, (size_t)T * m->d.num_emb * esz);
+    if (rc != WRK_OK) return rc;
+    m->layer_begin = layer; m->layer_end = layer + 1; m->skip_embed = true;
+    if (mode == 1 && one_token_each && nseq == T && m->act_dtype == WRK_F16) rc = m->enqueue_fused_decode(st, T, 0, true, false, false, false, cursors[0] & 0xff);
+    else rc = m->enqueue_ops(st, T, 0, true, mode == 1);
+    m->layer_begin = 0; m->layer_end = 0xffffffffu; m->skip_embed = false;
+    if (rc != WRK_OK) return rc;
+    WRK_LAUNCH_CHECK(ctx);
+    WRK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return WRK_OK;
+}
+
+// TensorGpu::back on one buffer of the frame (names as examples/inspect.rs:208-248: x, att_x, att_r, ..., ffn_v; plus head_x, head_o)
+int32_t wrk_v7_frame_read(wrk_ctx* ctx, wrk_v7_model* m, const char* name, uint32_t T, void* dst, size_t capacity, size_t* bytes) {
+    if (!ctx || !m || !name || !bytes) return WRK_E_ARG;
+    LOCK(ctx);
+    WRK_ARG(ctx, m->scratch && T >= 1 && T <= m->scratch_tokens, "no frame of %u tokens has been run", T);
+    const uint32_t D = m->d.num_emb, F = m->d.num_hidden;
+    const V7Scratch& s = m->s;
+    struct { const char* n; const void* p; uint32_t c; } tab[] = {
+        {"x", s.x, D}, {"att_x", s.att_x, D}, {"att_v0", s.att_v0, D}, {"att_rx", s.rx, D}, {"att_wx", s.wx, D}, {"att_kx", s.kx, D},
+        {"att_vx", s.vx, D}, {"att_ax", s.ax, D}, {"att_gx", s.gx, D}, {"att_r", s.r, D}, {"att_w", s.w, D}, {"att_k", s.k, D}, {"att_v", s.v, D},
+        {"att_a", s.a, D}, {"att_g", s.g, D}, {"att_o", s.o, D}, {"att_kk", s.kk, D}, {"att_vv", s.vv, D}, {"att_n", s.n, 4 * D},
+        {"aux_w", s.aux_w, m->d.lora_w}, {"aux_a", s.aux_a, m->d.lora_a}, {"aux_g", s.aux_g, m->d.lora_g}, {"aux_v", s.aux_v, m->d.lora_v},
+        {"ffn_x", s.ffn_x, D}, {"ffn_kx", s.ffn_kx, D}, {"ffn_k", s.ffn_k, F}, {"ffn_v", s.ffn_v, D}, {"att_x_ln", s.ln_tmp, D}};
+    const size_t esz = m->act_dtype == WRK_F32 ? 4 : 2;
+    for (auto& e : tab)
+        if (strcmp(e.n, name) == 0) {
+            const size_t n = (size_t)e.c * T * esz;
+            *bytes = n;
+            if (!dst) return WRK_OK;
+            WRK_ARG(ctx, capacity >= n, "frame buffer %s needs %zu bytes, capacity %zu", name, n, capacity);
+            WRK_HIP(ctx, hipSetDevice(ctx->device));
+            WRK_HIP(ctx, hipMemcpyAsync(dst, e.p, n, hipMemcpyDeviceToHost, ctx->stream));
+            WRK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            return WRK_OK;
+        }
+    return wrk_fail(ctx, WRK_E_ARG, "no frame buffer named %s", name);
 }
 
 int32_t wrk_v7_generate_greedy(wrk_ctx* ctx, wrk_v7_model* m, wrk_v7_state* st, const uint32_t* first_tokens, uint32_t B,
@@ -546,15 +639,15 @@ int32_t wrk_v7_generate_greedy(wrk_ctx* ctx, wrk_v7_model* m, wrk_v7_state* st, 
     const bool eager = ng && ng[0] == '1';
     wrk::timing_slot(ctx, nullptr);     // WRK_TIMING=1: allocate the stamp buffer outside the capture
     auto enqueue_step = [&]() -> int32_t {
-        if (mode == 1) return m->enqueue_fused_decode(st, B, B, true, true, true, true, 0);
-        wrk::gather_rows_f16(ctx->stream, m->emb->ptr, m->s.tokens, m->s.input, D, B);
+        if (mode == 1 && m->act_dtype == WRK_F16) return m->enqueue_fused_decode(st, B, B, true, true, true, true, 0);
+        wrk::gather_rows_f16(ctx->op_stream(), m->emb->ptr, m->s.tokens, m->s.input, D, B);
         int32_t r = m->enqueue_ops(st, B, B, true);
         if (r != WRK_OK) return r;
-        wrk::argmax_rows(ctx->stream, m->s.head_o, V, V, B, m->s.argmax);
-        wrk::advance_tokens(ctx->stream, m->s.argmax, m->s.tokens, m->history, m->s.counter, B);
+        wrk::argmax_rows(ctx->op_stream(), m->s.head_o, V, V, B, m->s.argmax);
+        wrk::advance_tokens(ctx->op_stream(), m->s.argmax, m->s.tokens, m->history, m->s.counter, B);
         return WRK_OK;
     };
-    const wrk_v7_model::GraphKey key{st->uid, B, mode};
+    const wrk_v7_model::GraphKey key{st->uid, B, mode | (m->act_dtype == WRK_F32 ? 4u : 0u)};
     wrk_program* prog = nullptr;
     if (!eager) {
         auto it = m->graphs.find(key);

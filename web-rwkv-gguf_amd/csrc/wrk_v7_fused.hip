@@ -402,7 +402,7 @@ static wrk::MatJob job(const wrk_matrix* m, DTensor in, DTensor out, uint32_t ac
 int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_t NH, bool identity_headers, bool from_tokens,
                                             bool want_argmax, bool advance, uint32_t cursor0_batch) {
     using namespace wrk;
-    hipStream_t q = ctx->stream;
+    hipStream_t q = ctx->op_stream();
     const uint32_t D = d.num_emb, F = d.num_hidden, H = d.num_head, S = D / H, V = d.num_vocab;
     // what the fused kernels assume; anything else takes the op-by-op path
     bool ok = (D % 8 == 0) && D <= 8192 && d.lora_w % 8 == 0 && d.lora_a % 8 == 0 && d.lora_g % 8 == 0 && d.lora_v % 8 == 0 &&
@@ -442,7 +442,7 @@ int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_
     } while (0)
 
     // embed: gather (device table) + LN(ln0) -> x   (v7.rs:438-474, 649-659)
-    {
+    if (!skip_embed) {
         LnMixParams P{};
         if (from_tokens) { P.src = (const f16*)emb->ptr; P.ids = s.tokens; }
         else P.src = (const f16*)s.input;
@@ -450,7 +450,7 @@ int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_
         P.d = D; P.nmix = 0; P.ln_out = (f16*)s.x;
         LN(P, T);
     }
-    for (uint32_t li = 0; li < d.num_layer; ++li) {
+    for (uint32_t li = layer_begin; li < d.num_layer && li < layer_end; ++li) {
         const wrk_v7_layer_desc& L = layers[li];
         float* lst = st->layer_ptr(li);
         // batch-1 decode folds LN + token shift into the prologue of the matvec that consumes them (5 launches per layer

@@ -354,6 +354,16 @@ struct TensorInfo {
         const size_t bs = block_size(type), ts = type_size(type);
         return bs == 1 ? num_elements() * ts : (num_elements() / bs) * ts;
     }
+    // dims and offsets come from the file: every product / sum is overflow-checked before a pointer is formed from it
+    // (a crafted offset near 2^64 would otherwise wrap past the range check and yield a pointer before the mapping)
+    bool checked_sizes(uint64_t& elems, uint64_t& bytes) const {
+        elems = 1;
+        for (uint64_t d : dims)
+            if (__builtin_mul_overflow(elems, d, &elems)) return false;
+        const uint64_t bs = block_size(type), ts = type_size(type);
+        if (bs == 0 || ts == 0) { bytes = 0; return true; }      // unknown type: rejected when the tensor is read
+        return !__builtin_mul_overflow(elems / bs, ts, &bytes);
+    }
 };
 
 struct MetaValue { int kind = 0; uint64_t u = 0; double f = 0; std::string s; };    // kind: 1 uint, 2 int, 3 float, 4 bool, 5 string, 6 array
@@ -452,9 +462,23 @@ struct wrk_gguf {
             name_map[g] = g;
         }
         // every tensor must lie inside the file: the loader hands these pointers to the device
+        if (tensor_data_offset > size) return fail(WRK_E_ARG, "tensor data offset %llu exceeds the file", (unsigned long long)tensor_data_offset);
+        const uint64_t room = size - tensor_data_offset;
         for (auto& kv : tensors) {
             const TensorInfo& ti = kv.second;
-            if (tensor_data_offset + ti.offset + ti.data_size() > size) return fail(WRK_E_ARG, "tensor %s exceeds the file", ti.name.c_str());
+            uint64_t elems, bytes;
+            if (!ti.checked_sizes(elems, bytes)) return fail(WRK_E_ARG, "tensor %s: dimensions overflow", ti.name.c_str());
+            if (ti.offset > room || bytes > room - ti.offset) return fail(WRK_E_ARG, "tensor %s exceeds the file", ti.name.c_str());
+        }
+        // fused time_maa tensors are read as six [D] slices (try_get_fused_slice, gguf.rs:1545-1571): they must hold them
+        for (auto& kv : name_map) {
+            const std::string sfx = ".att.time_maa";
+            if (kv.first.size() < sfx.size() || kv.first.compare(kv.first.size() - sfx.size(), sfx.size(), sfx) != 0) continue;
+            const TensorInfo& ti = tensors[kv.second];
+            uint64_t elems, bytes;
+            ti.checked_sizes(elems, bytes);
+            if (ti.dims.empty() || ti.dims[0] == 0 || elems / ti.dims[0] < 6)
+                return fail(WRK_E_ARG, "tensor %s: a fused lerp tensor must hold 6 slices of dims[0] elements", ti.name.c_str());
         }
         return WRK_OK;
     }

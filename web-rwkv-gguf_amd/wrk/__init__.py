@@ -123,6 +123,9 @@ HIP_SYMBOLS = {
     "wrk_v7_state_write": (C.c_int32, [_P, _P, C.c_uint32, _P]),
     "wrk_v7_state_back": (C.c_int32, [_P, _P, C.c_uint32, _f32p]),
     "wrk_v7_infer": (C.c_int32, [_P, _P, _P, _u32p, C.POINTER(C.c_uint16), _u32p, C.c_uint32, _u32p, C.c_uint32, _f32p, _u32p, C.c_uint32]),
+    "wrk_v7_model_set_frame_dtype": (C.c_int32, [_P, _P, C.c_uint32]),
+    "wrk_v7_infer_layer": (C.c_int32, [_P, _P, _P, C.c_uint32, _P, _P, _u32p, C.c_uint32, C.c_uint32]),
+    "wrk_v7_frame_read": (C.c_int32, [_P, _P, C.c_char_p, C.c_uint32, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "wrk_v7_generate_greedy": (C.c_int32, [_P, _P, _P, _u32p, C.c_uint32, C.c_uint32, _u32p, _f32p, _f32p, C.c_uint32]),
     "wrk_op_transpose": (C.c_int32, [_P, _TP, _TP]),
     "wrk_op_time_mix_v6": (C.c_int32, [_P, _P, _TP, _P, _TP, _TP, _TP, _TP, _TP]),
@@ -205,6 +208,20 @@ class Context:
             hip.wrk_ctx_destroy(self.h)
             self.h = None
 
+    # -- programs
+    def encode(self, build) -> "Program":
+        """`Context::encode(&TensorOp)` (ops.rs:79-143): run `build()` (which calls `TensorOp.*` / `matmul_op`) with the ops
+        recorded into a `Program` instead of executed.  Safe from several threads at once: a capture belongs to the calling
+        thread and records on a private stream (runtime/mod.rs:139-167 encodes on spawn_blocking workers)."""
+        self.check(hip.wrk_capture_begin(self.h))
+        try:
+            build()
+        finally:
+            h = _P()
+            rc = hip.wrk_capture_end(self.h, C.byref(h))
+        self.check(rc)
+        return Program(self, h)
+
     # -- tensors
     def tensor(self, array: np.ndarray, shape: Optional[Sequence[int]] = None) -> "Tensor":
         """context.tensor_from_data: numpy float16/float32 array; `shape` is [x fastest, y, z, w]."""
@@ -223,6 +240,25 @@ class Context:
     def buffer(self, array: np.ndarray) -> "Buffer":
         a = np.ascontiguousarray(array)
         return Buffer(self, a.nbytes, a)
+
+
+class Program:
+    """The `Vec<CommandBuffer>` an `RnnJob` keeps (v7.rs:423-432): a captured hipGraph; `launch` == `queue.submit`."""
+
+    def __init__(self, ctx: Context, h):
+        self.ctx, self.h = ctx, h
+
+    def launch(self):
+        self.ctx.check(hip.wrk_program_launch(self.ctx.h, self.h))
+
+    def __del__(self):
+        try:
+            if self.h and self.ctx.h:
+                self.ctx.sync()
+                hip.wrk_program_destroy(self.h)
+        except Exception:
+            pass
+        self.h = None
 
 
 class Buffer:
@@ -637,6 +673,29 @@ class Runtime:
         self.ctx.check(fn(self.ctx.h, mdl, self.state, _ptr(t, _u32p), None, _ptr(c, _u32p), t.size,
                           _ptr(h, _u32p), h.size, _ptr(logits, _f32p), _ptr(am, _u32p) if want_argmax else None, mode))
         return (logits[: h.size], am[: h.size]) if want_argmax else logits[: h.size]
+
+    def set_frame_dtype(self, dtype: int):
+        """`Bundle::<f16>` (F16, default) or `Bundle::<f32>` (F32) -- v7.rs:281-364 is generic over the activation type."""
+        self.ctx.check(hip.wrk_v7_model_set_frame_dtype(self.ctx.h, self.model, dtype))
+        self.frame_dtype = dtype
+
+    def infer_layer(self, layer: int, x: np.ndarray, v_first: Optional[np.ndarray], cursors, mode: int = 0):
+        """Teacher-forced run of one layer on the layer input `x` [T, D] (and the layer-0 value `v_first`)."""
+        dt = np.float32 if getattr(self, "frame_dtype", F16) == F32 else np.float16
+        xa = np.ascontiguousarray(x, dtype=dt)
+        va = np.ascontiguousarray(v_first, dtype=dt) if v_first is not None else None
+        c = _u32(cursors)
+        self.ctx.check(hip.wrk_v7_infer_layer(self.ctx.h, self.model, self.state, layer, xa.ctypes.data_as(_P),
+                                              va.ctypes.data_as(_P) if va is not None else None, _ptr(c, _u32p), c.size, mode))
+
+    def frame(self, name: str, num_token: int) -> np.ndarray:
+        """One `Runtime<F>` buffer of the last job, [T, C] (names: examples/inspect.rs:208-248)."""
+        dt = np.float32 if getattr(self, "frame_dtype", F16) == F32 else np.float16
+        n = C.c_size_t()
+        self.ctx.check(hip.wrk_v7_frame_read(self.ctx.h, self.model, name.encode(), num_token, None, 0, C.byref(n)))
+        out = np.empty(n.value // np.dtype(dt).itemsize, dt)
+        self.ctx.check(hip.wrk_v7_frame_read(self.ctx.h, self.model, name.encode(), num_token, out.ctypes.data_as(_P), out.nbytes, C.byref(n)))
+        return out.reshape(num_token, -1)
 
     def generate_greedy(self, first_tokens, steps: int, mode: int = 1, want_logits: bool = False):
         """Device-resident greedy loop; returns (tokens [steps, B], elapsed_ms[, last logits [B, V]])."""
