@@ -65,7 +65,7 @@ class Job:
 
 
 def test_concurrent_encoders_launcher_and_uploader(ctx):
-    ja = Job(ctx, 1, 512, 384, 1, "Q4_K", 3)
+    ja = Job(ctx, 1, 512, 384, 1, "Q4_K", 2)       # same op count as jb: the encoders meet after every op
     jb = Job(ctx, 2, 768, 256, 8, "F16", 2)
     jc = Job(ctx, 3, 256, 512, 2, "Q6_K", 1)
     # serial references (eager)

@@ -93,6 +93,12 @@ def test_channel_mix_v6(ctx):
     close16(xt.back().reshape(T, C), O.r16(O.sigmoid(rr.astype(np.float32)) * v.astype(np.float32)), 2)
 
 
+# FIXED bars per fixture (no sliding bar).  2 layers: the V7 bars.  7 layers: an f16 flip propagates through more
+# layers -- the oracle against ITSELF with f64 matmul accumulation differs by 8.1e-3 max / 1.9e-3 mean on this fixture (printed below
+# as a diagnostic, not used as a bar) -- so the depth-7 bars are 2.5e-2 / 5e-3.
+V6_BARS = {"tiny": (1e-2, 1.5e-3), "small": (2.5e-2, 5e-3)}
+
+
 @pytest.mark.parametrize("name,weights,kw", [
     ("tiny", wrk.WEIGHTS_INLINE, {}),
     ("tiny", wrk.WEIGHTS_INLINE_F16, {}),
@@ -110,16 +116,15 @@ def test_v6_prefill_then_greedy_decode(ctx, name, weights, kw):
     got = rt.infer(wrk.RnnInput([p0, p1], 32))
     want = oracle.infer_chunk([p0, p1], [18, 23])
 
-    # Noise floor of the arithmetic itself: the same oracle with its matmuls accumulated in f64 instead of f32
-    # (only the last bit of each f32 sum moves, but f16 stores flip and the flips propagate; grows with depth:
-    # 2.6e-3 max on the 2-layer model, 8.1e-3 max / 1.9e-3 mean on the 7-layer one).  The HIP path must be as
-    # close to the oracle as the oracle is to itself.
+    # Diagnostic only: the noise floor of the arithmetic itself -- the same oracle with its matmuls accumulated in f64 instead
+    # of f32 (only the last bit of each f32 sum moves, but f16 stores flip and the flips propagate with depth).
     class F64Acc(O6.V6Runtime):
         def _mm(self, w, x, act="none", f32_out=False):
             y = O.ACT[act]((x.astype(np.float64) @ w.T.astype(np.float64)).astype(np.float32))
             return y if f32_out else self.rnd(y)
     self_d = np.abs(F64Acc(model, 2, act_f16=True).infer_chunk([p0, p1], [18, 23]) - want)
-    tol_max, tol_mean = max(LOGIT_TOL, 2.5 * float(self_d.max())), max(LOGIT_MEAN_TOL, 2.5 * float(self_d.mean()))
+    print(f"v6 {name}: oracle f32-vs-f64 accumulation moves the logits by max {self_d.max():.2e} / mean {self_d.mean():.2e}")
+    tol_max, tol_mean = V6_BARS[name]
     toks = []
     for b in range(2):
         d = np.abs(got[b][0] - want[b])
