@@ -92,8 +92,11 @@ def run_case(ctx, name, weights, kw, mode, chunk_lens, steps):
     decode = all(n == 1 for n in chunk_lens)
     if mode == 0:
         table = MODE0
+    elif decode and T == 1:
+        # batch-1 decode: the split head kernel hands y = WKV output (pre group norm) and the gate to W_o's prologue
+        table = [(b, "wkv" if b == "att_x" else k, d) for b, k, d in MODE1] + [("att_g", "g", False)]
     elif decode:        # with several sequences LN + shifts run as their own launch and LN(x) is not stored separately
-        table = MODE1 if T == 1 else [e for e in MODE1 if e[0] not in ("att_x_ln", "ffn_x")]
+        table = [e for e in MODE1 if e[0] not in ("att_x_ln", "ffn_x")]
     else:
         table = MERGED
     case = f"{name}/{weights}/{sorted(kw.items())}/mode{mode}/{chunk_lens}"

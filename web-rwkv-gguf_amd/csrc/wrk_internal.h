@@ -186,6 +186,8 @@ struct MatJob {
     uint32_t* amax_idx = nullptr;
     // fused decode prologue / epilogue (single input vector only; matvec() returns -3 if it cannot honour them)
     uint32_t pro = 0;               // 1: input = mix(LN(in; ln_w, ln_b, pro_eps), prev, mixw)
+                                    // 2: input = mixw * r16(r16(GN64(in; ln_w, ln_b, pro_eps)) + prev): the post-WKV stage of a split head
+                                    //    (in = WKV output, prev = f32 time_first term, mixw = gate), dmv kernels only
     float pro_eps = 0.0f;
     const void *ln_w = nullptr, *ln_b = nullptr, *mixw = nullptr;
     const float* prev = nullptr;    // f32 shift-state row of this sequence

@@ -987,7 +987,10 @@ __device__ __forceinline__ void dmv_body(const DJob J, unsigned char* smem) {
     const uint32_t fin_row = min(KS == 1 ? row_of(lane & 3u) : r0 + (tid & 31u), r1 - 1);
     const uint32_t fl = J.flags;
     uint32_t res_bits = 0, carry_bits = 0, gate_bits = 0;
-    constexpr int VPT = PRO > 0 ? PRO : 1;
+    // PRO: 0 none | 1, 2: layer norm + token shift, 1 / 2 vectors per thread (K <= 2048 / 4096) | 3, 4: the post-WKV stage of a
+    // split head (group norm over 64-channel heads + time_first bonus + gate), 1 / 2 vectors per thread
+    constexpr int VPT = PRO == 0 ? 1 : ((PRO - 1) % 2 + 1);
+    constexpr bool GN = PRO >= 3;
     f16x8 xv[VPT], wv[VPT], bv[VPT], mv[VPT];
     f32x4 pv[VPT][2];
     f16 c0h = (f16)0.0f;
@@ -1004,7 +1007,7 @@ __device__ __forceinline__ void dmv_body(const DJob J, unsigned char* smem) {
             pv[v][0] = *(const f32x4*)(J.prev + i * 8);
             pv[v][1] = *(const f32x4*)(J.prev + i * 8 + 4);
         }
-        c0h = xin[0];
+        if (!GN) c0h = xin[0];
     } else {
 #pragma unroll
         for (int ci = 0; ci < XI; ++ci) x[ci] = load_x<KIND>(xin, min(cbase + CSTEP * ci, nch - 1), true);
@@ -1021,8 +1024,40 @@ __device__ __forceinline__ void dmv_body(const DJob J, unsigned char* smem) {
         gate_bits = (has_gate ? (const uint16_t*)J.gate : (const uint16_t*)xin)[has_gate ? fin_row : 0u];
     }
 
+    // ---- (2a) split-head prologue (K3): x_in = g * r16(r16(GN(y)) + tt)  with y = WKV output (f16), tt = (sum_j r_k k r) * v (f32),
+    //      g = gate (f16); a head is 64 channels = 8 threads of 8 channels, so the statistics are three DPP steps -- no barrier
+    if (GN) {
+        f16* xs = (f16*)(smem + 576);
+        const uint32_t nvec = K >> 3;
+#pragma unroll
+        for (int v = 0; v < VPT; ++v) {
+            float y[8], s1 = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { y[e] = (float)xv[v][e]; s1 += y[e]; }
+            s1 += dpp_f32<0xB1>(s1); s1 += dpp_f32<0x4E>(s1); s1 += dpp_f32<0x141>(s1);      // 8-lane sum (quad, quad pair)
+            const float mean = s1 * (1.0f / 64.0f);
+            float s2 = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { y[e] -= mean; s2 = __builtin_fmaf(y[e], y[e], s2); }
+            s2 += dpp_f32<0xB1>(s2); s2 += dpp_f32<0x4E>(s2); s2 += dpp_f32<0x141>(s2);
+            const float dev = 1.0f / sqrtf(s2 * (1.0f / 64.0f) + J.eps);
+            f16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float t = r16(__builtin_fmaf(y[e] * dev, (float)wv[v][e], (float)bv[v][e]));      // group_norm
+                t = r16(t + pv[v][e >> 2][e & 3]);                                                  // time_first_v7
+                o[e] = (f16)((float)mv[v][e] * t);                                                  // mul(g, x)
+            }
+            const uint32_t i = tid + 256u * v;
+            if (i < nvec) *(f16x8*)(xs + i * 8) = o;
+        }
+        for (uint32_t i = K + tid; i < kpad; i += 256) xs[i] = (f16)0.0f;
+        __syncthreads();
+#pragma unroll
+        for (int ci = 0; ci < XI; ++ci) x[ci] = load_x<KIND>(xs, min(cbase + CSTEP * ci, nch - 1), true);
+    }
     // ---- (2) prologue: layer norm + token shift of the input, once per workgroup, handed to the waves through LDS
-    if (PRO > 0) {
+    if (PRO > 0 && !GN) {
         f16* xs = (f16*)(smem + 576);
         float* red = (float*)(smem + 544);
         const uint32_t nvec = K >> 3;
@@ -1150,7 +1185,7 @@ __device__ __forceinline__ void dmv_body(const DJob J, unsigned char* smem) {
 template <int KA, int KB, bool R16, int XI, int KS, int PRO>
 __global__ void __launch_bounds__(256) dmv_kernel(uint32_t b1, uint32_t b2, uint32_t b3, uint32_t b4, uint32_t b5, uint32_t b6, uint32_t b7,
                                                   uint32_t kind_b_mask, const DParams P) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[576 + (PRO > 0 ? PRO * 4096 : 16)];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[576 + (PRO > 0 ? ((PRO - 1) % 2 + 1) * 4096 : 16)];
     const uint32_t b = blockIdx.x;
     const uint32_t ji = (b >= b1) + (b >= b2) + (b >= b3) + (b >= b4) + (b >= b5) + (b >= b6) + (b >= b7);
     const DJob J = P.jobs[ji];
@@ -1164,7 +1199,11 @@ template <int KA, int KB, int XI, int KS>
 static dmv_fn pick_dmv_pro(bool r16, int pro) {
 #define DMV_P(PRO_) (r16 ? (dmv_fn)dmv_kernel<KA, KB, true, XI, KS, PRO_> : (dmv_fn)dmv_kernel<KA, KB, false, XI, KS, PRO_>)
     if (KS == 4 || pro == 0) return DMV_P(0);
-    return pro == 1 ? DMV_P(1) : DMV_P(2);
+    if (pro == 1) return DMV_P(1);
+    if (pro == 2) return DMV_P(2);
+    // the split-head prologue only precedes W_o: a single-kind launch (the F16 pairing is not instantiated for it)
+    if (KA != KB) return nullptr;
+    return pro == 3 ? DMV_P(3) : DMV_P(4);
 #undef DMV_P
 }
 
@@ -1198,8 +1237,10 @@ static int launch_dmv(hipStream_t s, const MatvecParams& P, uint32_t total_wg, i
         if ((J.out.dtype != WRK_F16 && J.out.dtype != WRK_F32) || J.m == 0 || J.rows_per_wg == 0) return -1;
         const size_t ib = dense_base(J.in);
         if (ib & 7u) return -1;
-        const int jp = J.pro ? (J.k <= 2048 ? 1 : (J.k <= 4096 ? 2 : 3)) : 0;
-        if (jp == 3 || (pro >= 0 && jp != pro)) return -1;        // one prologue shape per launch
+        // MatJob::pro: 1 = layer norm + token shift, 2 = split-head post-WKV stage (group norm + time_first + gate)
+        const int jp = J.pro ? (J.k <= 2048 ? 1 : (J.k <= 4096 ? 2 : 9)) + (J.pro == 2 ? 2 : 0) : 0;
+        if (jp >= 9 || (pro >= 0 && jp != pro)) return -1;        // one prologue shape per launch
+        if (J.pro == 2 && (J.k & 63u)) return -1;
         pro = jp;
         if (J.rows_per_wg > 32) small_wg = false;
         const uint32_t kpad = (J.k + 15u) & ~15u;
@@ -1371,6 +1412,7 @@ static matvec_fn pick_reg(const MatvecParams& P, int quant, bool has_f16, bool r
         const JobDev& J = P.jobs[j];
         if (J.in.dtype != WRK_F16 || (J.k & 7u) || J.in.shape[1] * J.in.shape[2] != 1) return nullptr;
         if (J.pro && J.k > 4096) return nullptr;        // the staged input of the LN prologue is sized for K <= 4096
+        if (J.pro == 2) return nullptr;                 // the split-head prologue exists in the dmv kernels only
         const size_t base = ((size_t)J.in.offset[2] * J.in.stride[1] + J.in.offset[1]) * J.in.stride[0] + J.in.offset[0];
         if (base & 7u) return nullptr;
         const uint32_t kpad = (J.k + 15u) & ~15u;
@@ -1518,12 +1560,14 @@ int matvec(hipStream_t s, const MatJob* jobs, int njobs, int num_cu, bool dry_ru
     size_t smem = (size_t)nb * kpad * 2 + (size_t)nb * (kpad >> 4) * 4 + 64;      // inputs | per-16 sums | NF4 level table
     if (smem < 256) smem = 256;
     const uint32_t groups = (ntok + nb - 1) / nb;
+    int rc;
     switch (nb) {
-        case 8: return launch_matvec<8>(s, P, wg, groups, smem, dry_run, no_catchall);
-        case 4: return launch_matvec<4>(s, P, wg, groups, smem, dry_run, no_catchall);
-        case 2: return launch_matvec<2>(s, P, wg, groups, smem, dry_run, no_catchall);
-        default: return launch_matvec<1>(s, P, wg, groups, smem, dry_run, no_catchall);
+        case 8: rc = launch_matvec<8>(s, P, wg, groups, smem, dry_run, no_catchall); break;
+        case 4: rc = launch_matvec<4>(s, P, wg, groups, smem, dry_run, no_catchall); break;
+        case 2: rc = launch_matvec<2>(s, P, wg, groups, smem, dry_run, no_catchall); break;
+        default: rc = launch_matvec<1>(s, P, wg, groups, smem, dry_run, no_catchall); break;
     }
+    return rc;
 }
 
 // Jobs of several quantised kinds (a real Q4_K_M file keeps attn value / ffn value in Q6_K for half of the layers): one

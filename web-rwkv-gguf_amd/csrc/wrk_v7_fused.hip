@@ -294,6 +294,145 @@ __global__ void __launch_bounds__(256) head_kernel(const HeadParams P) {
     WRK_STAMP(P.dbg, 4);
 }
 
+// ------------------------------------------------------------------ K2, split: NS = 4 workgroups per head
+// The one-workgroup-per-head kernel pulls 97 KB (LoRA up-projection rows + state) through ONE CU, and a CU sustains ~25-70 GB/s
+// (MI355X_MICROARCH.md, "Indexed rows"): 2.4 us of its 3.9 us were that load (WRK_TIMING, round 2).  Here workgroup (head, q)
+// owns the value columns i = 16q .. 16q+15 of the head's state S[j][i] (all 64 rows j): sa_i = sum_j S[j][i] a_j and
+// y_i = sum_j r_j S'[j][i] are local to a column, so the WKV update needs no exchange between the four workgroups.  Each of
+// them recomputes the per-ROW quantities of the head (decay w_j, a_j, k_j, kk_j: the w2 / a2 LoRA rows, 24 KB, L2 hits for three
+// of the four: blockIdx = head + H*q puts them on one XCD), and loads only its 16 columns of g2 / v2 / state: 38 KB per CU.
+// The group norm needs all 64 outputs of the head, so it moves, with the time_first bonus and the gate, into the prologue of
+// the W_o matvec (dmv PRO 3/4); this kernel hands over y (f16, the value the op list stores in att_x), tt = (sum_j r_k k r) v (f32)
+// and g (f16).  Thread (wave w, lane j) holds S[j][16q + 4w .. +3]: both reductions over j are DPP wave sums, no LDS round trip.
+template <int GC>       // chunks of 128 gate-LoRA columns a 16-lane row group covers: rank_g <= 128 * GC
+__global__ void __launch_bounds__(256) head_split_kernel(const HeadParams P, float* __restrict__ tt_out, f16* __restrict__ g_out, uint32_t H) {
+    constexpr int S = 64, C = 16;
+    __shared__ float sh_r[S], sh_w[S], sh_k[S], sh_a[S], sh_b[S], sh_kk[S], sh_rkr[S];
+    __shared__ float sh_v[C], sh_g[C], sh_xx;
+    const uint32_t head = blockIdx.x % H, q = blockIdx.x / H, t = blockIdx.y, tid = threadIdx.x;
+    const uint32_t D = P.d, c0 = head * S, cq = c0 + C * q;
+    const uint32_t lane = tid & 63, wave = tid >> 6;
+    WRK_STAMP(P.dbg, 0);
+
+    // (1) cursor-independent loads first: w2 / a2 rows of all 64 channels (thread = (row, part)), g2 / v2 rows of the 16 own
+    //     columns (thread = (row16, p16)), per-channel scalars
+    const uint32_t row = tid >> 2, part = tid & 3u, ch = c0 + row;
+    LoraRegs<4> lw, la;
+    lora_load<4>(lw, (const f16*)((const uint8_t*)P.w2 + (size_t)ch * P.w2_rb), P.aux_w + (size_t)t * P.rw, P.rw, part);
+    lora_load<4>(la, (const f16*)((const uint8_t*)P.a2 + (size_t)ch * P.a2_rb), P.aux_a + (size_t)t * P.ra, P.ra, part);
+    const uint32_t row16 = tid >> 4, p16 = tid & 15u, chq = cq + row16;
+    f16x8 gw[GC], gx[GC], vw, vx;
+    {
+        const f16* grow = (const f16*)((const uint8_t*)P.g2 + (size_t)chq * P.g2_rb);
+        const f16* gaux = P.aux_g + (size_t)t * P.rg;
+#pragma unroll
+        for (int n = 0; n < GC; ++n) {
+            const uint32_t c = min(p16 * 8 + 128 * n, P.rg - 8);         // clamped: columns beyond the rank are masked in the dot
+            gw[n] = *(const f16x8*)(grow + c);
+            gx[n] = *(const f16x8*)(gaux + c);
+        }
+        const uint32_t cv = min(p16 * 8, P.rv - 8);
+        const f16* vrow = P.layer0 ? grow : (const f16*)((const uint8_t*)P.v2 + (size_t)chq * P.v2_rb);
+        vw = *(const f16x8*)(vrow + (P.layer0 ? 0 : cv));
+        vx = *(const f16x8*)((P.layer0 ? gaux : P.aux_v + (size_t)t * P.rv) + (P.layer0 ? 0 : cv));
+    }
+    const float w0 = (float)P.w0[ch], a0 = (float)P.a0[ch], kkw = (float)P.k_k[ch], kaw = (float)P.k_a[ch], rkw = (float)P.r_k[ch];
+    const float kraw = (float)P.k[(size_t)t * D + ch], rraw = (float)P.r[(size_t)t * D + ch];
+    float v = (float)P.v[(size_t)t * D + chq];
+    const float v0w = P.layer0 ? 0.0f : (float)P.v0[chq], vfirst = P.layer0 ? 0.0f : (float)P.v_first[(size_t)t * D + chq];
+    float shift = 0.0f;
+    if (P.shift_src && tid < C) shift = (float)P.shift_src[(size_t)t * D + cq + tid];
+
+    // (2) the state slice: thread (wave, lane = j) holds S[j][cq + 4*wave .. +3]; requested last, consumed last
+    const uint32_t batch = P.batch1 ? P.batch1 - 1 : (P.cursors[t] & 0xffu);
+    float* st = P.state + ((size_t)batch * (S + 2) + 1 + lane) * D + cq + 4 * wave;
+    f32x4 Sv = *(const f32x4*)st;
+
+    {
+        const float dw = lora_dot<4>(lw, P.rw, part);
+        const float da = lora_dot<4>(la, P.ra, part);
+        if (part == 0) {
+            const float w = r16(w0 + r16(dw));                                           // add(w0, w)
+            const float a = r16(act_sigmoid(a0 + r16(da)));                              // add_activate(.., Sigmoid)
+            const float kc = r16(kraw * (1.0f + (a - 1.0f) * kaw));                      // control_k_v7
+            sh_w[row] = __expf(-0.606531f * act_sigmoid(w));
+            sh_a[row] = a;
+            sh_r[row] = rraw;
+            sh_kk[row] = r16(kkw * kraw);                                                // mul(k_k, kk)
+            sh_k[row] = kc;
+            sh_rkr[row] = rkw * kc * rraw;                                               // time_first's summand
+        }
+        // gate / value-residual LoRA rows of the 16 own columns: 16 lanes per row
+        float dg = 0.0f, dv = 0.0f;
+#pragma unroll
+        for (int n = 0; n < GC; ++n)
+            if (p16 * 8 + 128 * n < P.rg) {
+                dg = __builtin_amdgcn_fdot2(__builtin_shufflevector(gw[n], gw[n], 0, 1), __builtin_shufflevector(gx[n], gx[n], 0, 1), dg, false);
+                dg = __builtin_amdgcn_fdot2(__builtin_shufflevector(gw[n], gw[n], 2, 3), __builtin_shufflevector(gx[n], gx[n], 2, 3), dg, false);
+                dg = __builtin_amdgcn_fdot2(__builtin_shufflevector(gw[n], gw[n], 4, 5), __builtin_shufflevector(gx[n], gx[n], 4, 5), dg, false);
+                dg = __builtin_amdgcn_fdot2(__builtin_shufflevector(gw[n], gw[n], 6, 7), __builtin_shufflevector(gx[n], gx[n], 6, 7), dg, false);
+            }
+        if (!P.layer0 && p16 * 8 < P.rv) {
+            dv = __builtin_amdgcn_fdot2(__builtin_shufflevector(vw, vw, 0, 1), __builtin_shufflevector(vx, vx, 0, 1), dv, false);
+            dv = __builtin_amdgcn_fdot2(__builtin_shufflevector(vw, vw, 2, 3), __builtin_shufflevector(vx, vx, 2, 3), dv, false);
+            dv = __builtin_amdgcn_fdot2(__builtin_shufflevector(vw, vw, 4, 5), __builtin_shufflevector(vx, vx, 4, 5), dv, false);
+            dv = __builtin_amdgcn_fdot2(__builtin_shufflevector(vw, vw, 6, 7), __builtin_shufflevector(vx, vx, 6, 7), dv, false);
+        }
+        // sums over the 16 lanes of a DPP row (all lanes of the row end up with the total)
+        dg += dpp_f32<0xB1>(dg); dg += dpp_f32<0x4E>(dg); dg += dpp_f32<0x141>(dg); dg += dpp_f32<0x140>(dg);
+        dv += dpp_f32<0xB1>(dv); dv += dpp_f32<0x4E>(dv); dv += dpp_f32<0x141>(dv); dv += dpp_f32<0x140>(dv);
+        if (p16 == 0) {
+            if (P.layer0) P.v_first[(size_t)t * D + chq] = (f16)v;                       // blit(att_v, att_v0)
+            else {
+                const float vv = r16(act_sigmoid(v0w + r16(dv)));
+                v = r16(wgsl_mix(v, vfirst, vv));                                        // lerp(att_v0, att_v, att_vv, reversed)
+            }
+            sh_v[row16] = v;
+            sh_g[row16] = r16(dg);
+        }
+    }
+    if (P.shift_src && tid < C) P.state[(size_t)batch * (S + 2) * D + cq + tid] = shift;
+    WRK_STAMP(P.dbg, 1);
+    __syncthreads();
+    if (wave == 0) {       // kk <- l2_norm(kk) over the head; a~ = -kk, b~ = kk * a; xx = sum_j r_k k r
+        const float kkv = sh_kk[lane];
+        const float nrm = 1.0f / sqrtf(wave_sum(kkv * kkv) + P.l2_eps);
+        const float kkn = r16(kkv * nrm);
+        const float a = sh_a[lane];
+        sh_a[lane] = -kkn;
+        sh_b[lane] = kkn * a;
+        const float xx = wave_sum(sh_rkr[lane]);
+        if (lane == 0) sh_xx = xx;
+    }
+    __syncthreads();
+    WRK_STAMP(P.dbg, 2);
+    {
+        const float aj = sh_a[lane], bj = sh_b[lane], wj = sh_w[lane], kj = sh_k[lane], rj = sh_r[lane];
+        float sa[4], y[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) sa[c] = wave_sum(Sv[c] * aj);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float s = Sv[c] * wj + kj * sh_v[4 * wave + c] + sa[c] * bj;
+            Sv[c] = s;
+            y[c] = rj * s;
+        }
+        *(f32x4*)st = Sv;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) y[c] = wave_sum(y[c]);
+        WRK_STAMP(P.dbg, 3);
+        if (lane < 4) {
+            const float yv = lane == 0 ? y[0] : (lane == 1 ? y[1] : (lane == 2 ? y[2] : y[3]));
+            const uint32_t i = 4 * wave + lane;
+            const size_t o = (size_t)t * D + cq + i;
+            P.out[o] = (f16)yv;                                                           // att_x <- y (f16 store)
+            tt_out[o] = sh_xx * sh_v[i];                                                  // time_first: + (sum_j r_k k r) * v, added after the group norm
+            g_out[o] = (f16)sh_g[i];
+        }
+    }
+    WRK_STAMP(P.dbg, 4);
+}
+
 // ------------------------------------------------------------------ greedy sampling, stage 2
 // Reduces the per-workgroup (max, first index) partials written by the head matvec, stores the token,
 // and (optionally) advances the device-resident generation loop: tokens <- argmax, history, counter.
@@ -470,6 +609,17 @@ int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_
             single = matvec_grouped(q, k1, li ? 7 : 6, ctx->num_cu, true) == 0 && matvec(q, &k5, 1, ctx->num_cu, true) == 0 &&
                      matvec(q, &k6, 1, ctx->num_cu, true) == 0;
         }
+        // split head (4 workgroups per head, group norm in W_o's prologue): batch-1 decode whose W_o launch the dmv kernels take
+        static const bool want_split = [] { const char* e = getenv("WRK_SPLIT_HEAD"); return !(e && e[0] == '0'); }();
+        bool split_head = want_split && single && d.lora_w >= 8 && d.lora_a >= 8 && d.lora_g >= 8 && d.lora_v >= 8 && d.lora_g <= 512;
+        if (split_head) {
+            MatJob k3 = job(L.w_o, vec(s.att_x), vec(s.x), 0);
+            k3.has_res = 1; k3.res = vec(s.x);
+            k3.pro = 2; k3.ln_w = L.gn_w->ptr; k3.ln_b = L.gn_b->ptr; k3.mixw = s.g; k3.prev = (const float*)s.n;
+            split_head = matvec(q, &k3, 1, ctx->num_cu, true) == 0;
+        }
+        // (next-launch weight prefetch -- every launch touching the lines its successor will stream -- was built and measured in
+        // round 2: every edge made the token slower, profiles/r02_prefetch_ab.txt; HBM streaming is not what bounds batch 1)
         uint32_t batch0 = 0;
         if (single) batch0 = cursor0_batch;
         float* row0 = lst + (size_t)batch0 * (S + 2) * D;                    // att shift state of the sequence
@@ -520,12 +670,19 @@ int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_
             P.shift_src = single ? (const f16*)s.ln_tmp : nullptr;     // fused K0: the state carry happens here
             P.batch1 = single ? batch0 + 1 : 0;
             P.dbg = li == TIMED_LAYER ? wrk::timing_slot(ctx, "K2 head: LoRA-2 + WKV7 + group norm") : nullptr;
-            if (d.lora_g <= 256) head_kernel<8><<<dim3(H, T), 256, 0, q>>>(P);
+            if (split_head) {
+                if (d.lora_g <= 256) head_split_kernel<2><<<dim3(H * 4, T), 256, 0, q>>>(P, (float*)s.n, (f16*)s.g, H);
+                else head_split_kernel<4><<<dim3(H * 4, T), 256, 0, q>>>(P, (float*)s.n, (f16*)s.g, H);
+            }
+            else if (d.lora_g <= 256) head_kernel<8><<<dim3(H, T), 256, 0, q>>>(P);
             else head_kernel<16><<<dim3(H, T), 256, 0, q>>>(P);
         }
         {   // K3: x += W_o . att_x
             MatJob j = job(L.w_o, vec(s.att_x), vec(s.x), WRK_ACT_NONE);
             j.has_res = 1; j.res = vec(s.x);
+            if (split_head) {       // group norm + time_first + gate of the split head kernel's hand-over, in the prologue
+                j.pro = 2; j.pro_eps = 64.0e-5f; j.ln_w = L.gn_w->ptr; j.ln_b = L.gn_b->ptr; j.mixw = s.g; j.prev = (const float*)s.n;
+            }
             if (li == TIMED_LAYER) j.dbg = wrk::timing_slot(ctx, "K3 w_o + residual");
             if (run_jobs(&j, 1) != 0) return wrk_fail(ctx, WRK_E_ARG, "fused K3 rejected");
         }
