@@ -69,7 +69,10 @@ struct GemmParams {
     uint32_t wg_begin;          // first workgroup (in x) of this job
     float scale;                // wrk_matrix::out_scale
     unsigned long long* dbg;    // WRK_TIMING build: stamps of this launch
-    DTensor in, out, res;       // [K, T, B], [M, T, B]
+    DTensor in, out, res;       // [K, T, B], [M, T, B]   (the LDS-tile kernels address through these)
+    // dense token stacks for the K-split kernel: token tok at base + tok * stride (elements)
+    const f16* x; const void* res_p; void* out_p;
+    uint32_t xs, rs, os, out32, res32;
 };
 
 constexpr int GEMM_MAX_JOBS = 8;
@@ -81,13 +84,17 @@ struct GemmBatch {
 // token index -> (t, b) of the [C, T, B] views
 __device__ __forceinline__ void tok_tb(const DTensor& d, uint32_t tok, uint32_t& t, uint32_t& b) { t = tok % d.shape[1]; b = tok / d.shape[1]; }
 
+// Round 2: every global load of this kernel is UNCONDITIONAL (token, row, block and k indices are clamped; dead blocks are
+// multiplied by zero scales, dead token columns are never stored) and every wave of a workgroup runs the same trip count.
+// The first version predicated its loads (`live ? load : zero`, `if (u < nmine) load_w`); the compiler then loses count of
+// the outstanding loads and waits `vmcnt(0)` in front of every use -- the ISA had one full memory round trip per 256-block.
+// Tensors are dense token stacks (checked on the host): token tok of the input / output / residual is `tok * stride`
+// elements from the base.
 template <int KIND, int NT, int NW>
 __device__ __forceinline__ void gemm_body(const GemmParams& P, float (*sh_tot)[NT][4][64]) {
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t r = lane & 15, g = lane >> 4;
-    // a workgroup owns 16 rows; its NW waves split K (wave w takes every NW-th block / step) and meet in LDS.  NW = 4, or
-    // 8 when a launch has few row tiles and long rows (ffn.value at 16 tokens: 128 workgroups x 32 blocks), so that a
-    // wave's serial chain stays ~4 blocks
     const uint32_t m0 = (blockIdx.x - P.wg_begin) * 16;
     WRK_STAMP(P.dbg, 0);
     const uint32_t row = min(m0 + r, P.m - 1);
@@ -95,95 +102,99 @@ __device__ __forceinline__ void gemm_body(const GemmParams& P, float (*sh_tot)[N
     const uint32_t n0 = blockIdx.y * 16 * NT;
     const uint32_t K = P.k, nb = K >> 8;
 
-    // B operand rows: token column c = lane & 15 of each tile
+    // B operand rows: token column c = lane & 15 of each tile (clamped: a dead column computes garbage that is never stored)
     const f16* xrow[NT];
-    bool xlive[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const uint32_t tok = n0 + 16 * t + r;
-        xlive[t] = tok < P.n;
-        uint32_t tt, bb;
-        tok_tb(P.in, xlive[t] ? tok : 0, tt, bb);
-        xrow[t] = (const f16*)P.in.p + dt_index(P.in, 0, tt, bb);
-    }
-    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    auto loadB = [&](int t, uint32_t koff) -> f16x8 { return xlive[t] ? *(const f16x8*)(xrow[t] + koff + 8 * g) : zero8; };
+    for (int t = 0; t < NT; ++t) xrow[t] = P.x + (size_t)min(n0 + 16 * t + r, P.n - 1) * P.xs + 8 * g;
+    auto loadB = [&](int t, uint32_t koff) -> f16x8 { return *(const f16x8*)(xrow[t] + koff); };
 
     f32x4v total[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) total[t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
 
-    // residual operands of the C elements this lane stores (wave 0 does the epilogue): requested now, with the first
-    // weights, instead of as a dependent load after the last MFMA (1.4 us in the WRK_TIMING trace)
-    float resv[NT][4];
-    if (P.has_res && wave == 0) {
+    // residual operands of the C elements this lane stores (wave 0 does the epilogue): raw bits, requested with the first weights
+    uint32_t resb[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) resb[t][i] = 0;
+    if (P.has_res) {        // uniform
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const uint32_t tok = n0 + 16 * t + r;
-            uint32_t rt, rb;
-            tok_tb(P.res, tok < P.n ? tok : 0, rt, rb);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) resv[t][i] = (tok < P.n && m0 + 4 * g + i < P.m) ? dt_load(P.res, dt_index(P.res, m0 + 4 * g + i, rt, rb)) : 0.0f;
+            const size_t ro = (size_t)min(n0 + 16 * t + r, P.n - 1) * P.rs + min(m0 + 4 * g, P.m - 4u);
+            if (P.res32) { const u32x4 v = *(const u32x4*)((const float*)P.res_p + ro); resb[t][0] = v.x; resb[t][1] = v.y; resb[t][2] = v.z; resb[t][3] = v.w; }
+            else { const u32x2 v = *(const u32x2*)((const f16*)P.res_p + ro); resb[t][0] = v.x & 0xffffu; resb[t][1] = v.x >> 16; resb[t][2] = v.y & 0xffffu; resb[t][3] = v.y >> 16; }
         }
     }
 
     if (KIND == WRK_MAT_F16) {
-        // this wave's 32-k steps are wave, wave + NW, ...; eight steps' fragments are requested together (one memory round
-        // trip per batch instead of one per step: the LoRA projections were the stragglers of the multi-matrix launch)
+        // this wave's 32-k steps are wave, wave + NW, ...; FB steps' fragments are requested together.  Steps beyond K are
+        // clamped to the last full fragment and their A fragment zeroed (a select, not a branch).
         const f16* wr = (const f16*)wrow;
         constexpr int FB = 8;
-        const uint32_t nsteps = K >> 5, mine = wave < nsteps ? (nsteps - wave + NW - 1) / NW : 0;
-        for (uint32_t i0 = 0; i0 < mine; i0 += FB) {
+        const uint32_t nsteps = (K + 31) >> 5, iters = (nsteps + NW - 1) / NW;
+        const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+        const uint32_t klast = K - 8;
+        for (uint32_t i0 = 0; i0 < iters; i0 += FB) {
             f16x8 a[FB], bf[NT <= 2 ? NT : 1][FB];
 #pragma unroll
             for (int u = 0; u < FB; ++u) {
-                const uint32_t k0 = 32 * (wave + NW * (i0 + u));
-                const bool ok = i0 + u < mine && k0 + 8 * g + 8 <= K;
-                a[u] = ok ? *(const f16x8*)(wr + k0 + 8 * g) : zero8;
+                const uint32_t k0 = 32 * (wave + NW * (i0 + u)) + 8 * g;
+                const bool ok = i0 + u < iters && k0 + 8 <= K;
+                const uint32_t kc = min(k0, klast);
+                const f16x8 av = *(const f16x8*)(wr + kc);
+                a[u] = ok ? av : zero8;
                 if (NT <= 2) {
 #pragma unroll
-                    for (int t = 0; t < (NT <= 2 ? NT : 1); ++t) bf[t][u] = ok ? loadB(t, k0) : zero8;
+                    for (int t = 0; t < (NT <= 2 ? NT : 1); ++t) bf[t][u] = *(const f16x8*)(xrow[t] - 8 * g + kc);
                 }
             }
 #pragma unroll
             for (int u = 0; u < FB; ++u) {
-                const uint32_t k0 = 32 * (wave + NW * (i0 + u));
-                const bool ok = i0 + u < mine && k0 + 8 * g + 8 <= K;
+                const uint32_t kc = min(32 * (wave + NW * (i0 + u)) + 8 * g, klast);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    const f16x8 bfr = NT <= 2 ? bf[NT <= 2 ? t : 0][u] : (ok ? loadB(t, k0) : zero8);
+                    const f16x8 bfr = NT <= 2 ? bf[NT <= 2 ? t : 0][u] : *(const f16x8*)(xrow[t] - 8 * g + kc);
                     total[t] = mfma16(a[u], bfr, total[t]);
                 }
             }
         }
     } else if (KIND == WRK_MAT_Q8_0) {
-        const uint32_t nblk = K >> 5;
-        for (uint32_t s = wave; s < nblk; s += NW) {
+        const uint32_t nblk = K >> 5, iters = (nblk + NW - 1) / NW;
+        const uint8_t* drow[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) drow[i] = P.w + (size_t)min(m0 + 4 * g + i, P.m - 1) * P.row_bytes + K;
+        for (uint32_t it = 0; it < iters; ++it) {
+            const uint32_t s0 = wave + NW * it, s = min(s0, nblk - 1);
             const u32x2 q = *(const u32x2*)(wrow + (size_t)s * 32 + 8 * g);
+            uint32_t db[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) db[i] = *(const uint16_t*)(drow[i] + (size_t)s * 2);
+            f16x8 bfr[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) bfr[t] = loadB(t, s * 32);
             // int8 -> (u - 128): subnormal u*2^-24, scaled by 2^15 to u*2^-9 (normal), minus 128*2^-9
             const f16x8 a = add8(mul8(codes8(q.x ^ 0x80808080u, q.y ^ 0x80808080u), 32768.0f), -0.25f);
-            // d of the C rows this lane owns: rows 4g..4g+3 of the wave
-            float dd[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint32_t rr = min(m0 + 4 * g + i, P.m - 1);
-                dd[i] = (float)*(const f16*)(P.w + (size_t)rr * P.row_bytes + K + (size_t)s * 2) * 512.0f;   // * 2^9
-            }
+            const float livef = s0 < nblk ? 512.0f : 0.0f;                       // * 2^9; a dead step contributes nothing
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const f32x4v acc = mfma16(a, loadB(t, s * 32), (f32x4v){0.f, 0.f, 0.f, 0.f});
+                const f32x4v acc = mfma16(a, bfr[t], (f32x4v){0.f, 0.f, 0.f, 0.f});
 #pragma unroll
-                for (int i = 0; i < 4; ++i) total[t][i] = __builtin_fmaf(dd[i], acc[i], total[t][i]);
+                for (int i = 0; i < 4; ++i) total[t][i] = __builtin_fmaf((float)__builtin_bit_cast(f16, (uint16_t)db[i]) * livef, acc[i], total[t][i]);
             }
         }
     } else if (KIND == WRK_MAT_INT8) {
         // web-rwkv Int8 (matmul_mat_int8, ops.rs:1072-1146): w = code / 255 * (max - min) + min per 128 elements.  The codes
         // (0..255, exact in f16) and a fragment of ones go through the matrix core; per 128-block
         //   total += (max - min) / 255 * sum(code * x) + min * sum(x).   Rows are block aligned (K % 128 == 0, host-checked).
-        const uint32_t nblk = K >> 7;
+        const uint32_t nblk = K >> 7, iters = (nblk + NW - 1) / NW;
         const f16 one = (f16)1.0f;
         const f16x8 ones = {one, one, one, one, one, one, one, one};
-        for (uint32_t b = wave; b < nblk; b += NW) {
+        const uint8_t* mrow[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mrow[i] = P.w + (size_t)min(m0 + 4 * g + i, P.m - 1) * P.row_bytes + K;
+        for (uint32_t it = 0; it < iters; ++it) {
+            const uint32_t b0 = wave + NW * it, b = min(b0, nblk - 1);
             f32x4v acc[NT], asum[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) { acc[t] = (f32x4v){0.f, 0.f, 0.f, 0.f}; asum[t] = (f32x4v){0.f, 0.f, 0.f, 0.f}; }
@@ -192,7 +203,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& P, float (*sh_tot)[N
             for (int j = 0; j < 4; ++j) q[j] = *(const u32x2*)(wrow + (size_t)b * 128 + j * 32 + 8 * g);
             uint32_t mm[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) mm[i] = *(const uint32_t*)(P.w + (size_t)min(m0 + 4 * g + i, P.m - 1) * P.row_bytes + K + (size_t)b * 4);
+            for (int i = 0; i < 4; ++i) mm[i] = *(const uint32_t*)(mrow[i] + (size_t)b * 4);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const f16x8 a = mul8(codes8(q[j].x, q[j].y), 32768.0f);       // code * 2^-9, exact
@@ -203,32 +214,53 @@ __device__ __forceinline__ void gemm_body(const GemmParams& P, float (*sh_tot)[N
                     asum[t] = mfma16(ones, bfr, asum[t]);
                 }
             }
+            const float livef = b0 < nblk ? 1.0f : 0.0f;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float mn = (float)__builtin_bit_cast(f16, (uint16_t)(mm[i] & 0xffffu)), mx = (float)__builtin_bit_cast(f16, (uint16_t)(mm[i] >> 16));
+                const float mn = (float)__builtin_bit_cast(f16, (uint16_t)(mm[i] & 0xffffu)) * livef, mx = (float)__builtin_bit_cast(f16, (uint16_t)(mm[i] >> 16)) * livef;
                 const float sc = (mx - mn) * (512.0f / 255.0f);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) total[t][i] += sc * acc[t][i] + mn * asum[t][i];
             }
         }
     } else if (KIND == WRK_MAT_Q6_K) {
-        for (uint32_t b = wave; b < nb; b += NW) {
+        const uint32_t iters = (nb + NW - 1) / NW;
+        const uint8_t* drow[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) drow[i] = P.w + (size_t)min(m0 + 4 * g + i, P.m - 1) * P.row_bytes + (size_t)nb * 208;
+        struct W6 { u32x2 ql[4]; u32x2 qh[2]; u32x4 sc; uint32_t d[4]; };
+        auto load_w6 = [&](W6& R, uint32_t b) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) R.ql[j] = *(const u32x2*)(wrow + (size_t)b * 128 + j * 32 + 8 * g);       // j = 2 n128 + (kq & 1)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) R.qh[h] = *(const u32x2*)(wrow + (size_t)nb * 128 + (size_t)b * 64 + h * 32 + 8 * g);
+            R.sc = *(const u32x4*)(wrow + (size_t)nb * 192 + (size_t)b * 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) R.d[i] = *(const uint16_t*)(drow[i] + (size_t)b * 2);
+        };
+        const uint32_t gsh = 8 * (g >> 1);       // scale byte of this lane's 16-element half of a 32-group
+        W6 Wc, Wn;
+        load_w6(Wc, min(wave, nb - 1));
+        for (uint32_t it = 0; it < iters; ++it) {
+            const uint32_t b0 = wave + NW * it, b = min(b0, nb - 1);
+            load_w6(Wn, min(b0 + NW, nb - 1));          // next block's weights in flight while this one is multiplied
             f32x4v acc[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int n128 = 0; n128 < 2; ++n128) {
-                const u32x2 qh = *(const u32x2*)(wrow + (size_t)nb * 128 + (size_t)b * 64 + n128 * 32 + 8 * g);
+                const u32x2 qh = Wc.qh[n128];
 #pragma unroll
                 for (int kq = 0; kq < 4; ++kq) {      // element group 128*n128 + 32*kq + (0..31)
-                    const u32x2 ql = *(const u32x2*)(wrow + (size_t)b * 128 + n128 * 64 + (kq & 1) * 32 + 8 * g);
+                    const u32x2 ql = Wc.ql[2 * n128 + (kq & 1)];
                     const uint32_t sh = 2 * kq;
                     uint32_t c0, c1;
                     if (kq < 2) { c0 = (ql.x & 0x0f0f0f0fu) | (((qh.x >> sh) & 0x03030303u) << 4); c1 = (ql.y & 0x0f0f0f0fu) | (((qh.y >> sh) & 0x03030303u) << 4); }
                     else { c0 = ((ql.x >> 4) & 0x0f0f0f0fu) | (((qh.x >> sh) & 0x03030303u) << 4); c1 = ((ql.y >> 4) & 0x0f0f0f0fu) | (((qh.y >> sh) & 0x03030303u) << 4); }
                     // c = code - 32 as c * 2^-9 (normal f16, exact)
                     const f16x8 c = add8(mul8(codes8(c0, c1), 32768.0f), -0.0625f);
-                    const int sc = (int)*(const int8_t*)(wrow + (size_t)nb * 192 + (size_t)b * 16 + n128 * 8 + (g >> 1) + 2 * kq);
+                    const uint32_t word = Wc.sc[2 * n128 + (kq >> 1)];
+                    const int sc = (int)(int8_t)((word >> (16 * (kq & 1) + gsh)) & 0xffu);
                     const int s1 = sc >> 1, s0 = sc & 1;            // sc = 2*s1 + s0
                     const f16x8 a1 = mul8(c, (float)(2 * s1)), a0 = mul8(c, (float)s0);
                     const uint32_t koff = b * 256 + n128 * 128 + kq * 32;
@@ -240,23 +272,18 @@ __device__ __forceinline__ void gemm_body(const GemmParams& P, float (*sh_tot)[N
                     }
                 }
             }
-            float dd[4];
+            const float livef = b0 < nb ? 512.0f : 0.0f;      // * 2^9
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const uint32_t rr = min(m0 + 4 * g + i, P.m - 1);
-                dd[i] = (float)*(const f16*)(P.w + (size_t)rr * P.row_bytes + (size_t)nb * 208 + (size_t)b * 2) * 512.0f;   // * 2^9
+                const float dd = (float)__builtin_bit_cast(f16, (uint16_t)Wc.d[i]) * livef;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) total[t][i] = __builtin_fmaf(dd, acc[t][i], total[t][i]);
             }
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) total[t][i] = __builtin_fmaf(dd[i], acc[t][i], total[t][i]);
+            Wc = Wn;
         }
     } else {   // Q4_K / Q5_K
         const uint32_t hoff = KIND == WRK_MAT_Q4_K ? nb * 128 : nb * 160;     // (d, dmin) plane
         const uint32_t soff = hoff + nb * 4;                                   // unpacked scales plane
-        // Loads of one 256-block.  Weights/scales (18 VGPRs) are prefetched FOUR blocks ahead and the B fragments one
-        // block ahead: a wave walks its blocks serially, so without depth every block costs a full memory round trip
-        // (rocprof round 1: 13 us for a 9 MB matrix x 16 tokens, i.e. latency, not bytes).
         struct WBlk {
             u32x2 q[4];             // quant bytes of this lane's 8 k per 64-element step
             u32x2 qh;               // Q5_K high bits
@@ -282,7 +309,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& P, float (*sh_tot)[N
                 for (int sb = 0; sb < 8; ++sb) R.bf[t][sb] = loadB(t, b * 256 + sb * 32);
         };
         // NT > 2 (prefill): B fragments are fetched per 64-k step instead (a whole block of them would be 128 VGPRs)
-        auto mul_blk = [&](const WBlk& R, const BBlk& X, uint32_t b) {
+        auto mul_blk = [&](const WBlk& R, const BBlk& X, uint32_t b, bool live) {
             f32x4v acc[NT], amin[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) { acc[t] = (f32x4v){0.f, 0.f, 0.f, 0.f}; amin[t] = (f32x4v){0.f, 0.f, 0.f, 0.f}; }
@@ -313,51 +340,53 @@ __device__ __forceinline__ void gemm_body(const GemmParams& P, float (*sh_tot)[N
                     amin[t] = mfma16(mhi, b1, amin[t]);
                 }
             }
-            // block epilogue for C rows 4g..4g+3: total += d * acc * 2^14 - dmin * acc_min
+            // block epilogue for C rows 4g..4g+3: total += d * acc * 2^14 - dmin * acc_min  (a dead block: zero scales)
+            const float livef = live ? 1.0f : 0.0f;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float d = (float)__builtin_bit_cast(f16, (uint16_t)(R.dd[i] & 0xffffu)) * 16384.0f;
-                const float dmin = (float)__builtin_bit_cast(f16, (uint16_t)(R.dd[i] >> 16));
+                const float d = (float)__builtin_bit_cast(f16, (uint16_t)(R.dd[i] & 0xffffu)) * (16384.0f * livef);
+                const float dmin = (float)__builtin_bit_cast(f16, (uint16_t)(R.dd[i] >> 16)) * livef;
 #pragma unroll
                 for (int t = 0; t < NT; ++t) total[t][i] += d * acc[t][i] - dmin * amin[t][i];
             }
         };
-        const uint32_t nmine = wave < nb ? (nb - wave + NW - 1) / NW : 0;      // blocks of this wave: wave, wave+NW, ...
+        // every wave runs ceil(nb / NW) blocks: wave, wave + NW, ... clamped to the last block (dead ones count zero)
+        const uint32_t iters = (nb + NW - 1) / NW;
+        auto blk = [&](uint32_t i) { return min(wave + NW * i, nb - 1); };
         WRK_STAMP(P.dbg, 1);
-        // prefetch depth by regime: few tokens = few waves per CU = latency-bound (deep); many tokens = register-bound
-        constexpr int WD = NT == 1 ? 4 : (NT == 2 ? 2 : 1);
-        WBlk W[WD];
-#pragma unroll
-        for (int u = 0; u < WD; ++u)
-            if ((uint32_t)u < nmine) load_w(W[u], wave + NW * u);
-        if (NT <= 2) {
-            constexpr int XD = NT == 1 ? 2 : 1;     // B fragments double-buffered only in the 16-token regime
-            BBlk X[XD];
-            if (XD == 2 && nmine) load_b(X[0], wave);
-            for (uint32_t i0 = 0; i0 < nmine; i0 += 4) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {       // unrolled by 4 so that every buffer index is a compile-time constant
-                    const uint32_t i = i0 + u;
-                    if (i >= nmine) break;
-                    const uint32_t b = wave + NW * i;
-                    if (XD == 2) { if (i + 1 < nmine) load_b(X[(u + 1) % XD], b + NW); }
-                    else load_b(X[0], b);
-                    mul_blk(W[u % WD], X[u % XD], b);
-                    if (i + WD < nmine) load_w(W[u % WD], b + NW * WD);
-                }
+        // weights TWO blocks ahead, B fragments one block ahead (16-token regime) or with the block (more tokens)
+        // (four blocks ahead measured slower at 16 tokens: 18.3 vs 15.9 us for ffn.value -- register pressure, round 2)
+        WBlk W0, W1;
+        load_w(W0, blk(0));
+        load_w(W1, blk(1));
+        if (NT == 1) {
+            BBlk X0, X1;
+            load_b(X0, blk(0));
+            for (uint32_t i = 0; i < iters; i += 2) {
+                load_b(X1, blk(i + 1));
+                mul_blk(W0, X0, blk(i), wave + NW * i < nb);
+                load_w(W0, blk(i + 2));
+                if (i + 1 >= iters) break;              // uniform over the workgroup
+                load_b(X0, blk(i + 2));
+                mul_blk(W1, X1, blk(i + 1), wave + NW * (i + 1) < nb);
+                load_w(W1, blk(i + 3));
             }
         } else {
-            BBlk X;     // unused
-            for (uint32_t i = 0; i < nmine; ++i) {
-                const uint32_t b = wave + NW * i;
-                mul_blk(W[0], X, b);
-                if (i + 1 < nmine) load_w(W[0], b + NW);
+            BBlk X;     // NT == 2: one block of B fragments, fetched with the block; NT > 2: unused
+            for (uint32_t i = 0; i < iters; i += 2) {
+                if (NT == 2) load_b(X, blk(i));
+                mul_blk(W0, X, blk(i), wave + NW * i < nb);
+                load_w(W0, blk(i + 2));
+                if (i + 1 >= iters) break;
+                if (NT == 2) load_b(X, blk(i + 1));
+                mul_blk(W1, X, blk(i + 1), wave + NW * (i + 1) < nb);
+                load_w(W1, blk(i + 3));
             }
         }
     }
 
     WRK_STAMP(P.dbg, 2);                // this wave's blocks are multiplied
-    // combine the four K slices
+    // combine the K slices
     if (wave > 0) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -382,15 +411,20 @@ __device__ __forceinline__ void gemm_body(const GemmParams& P, float (*sh_tot)[N
     for (int t = 0; t < NT; ++t) {
         const uint32_t tok = n0 + 16 * t + r;
         if (tok >= P.n) continue;
-        uint32_t tt, bb;
-        tok_tb(P.out, tok, tt, bb);
+        float o[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const uint32_t mr = m0 + 4 * g + i;
-            if (mr >= P.m) continue;
-            float o = act_apply(P.act, total[t][i] * P.scale);
-            if (P.has_res) o = dt_round(P.out, o) + resv[t][i];
-            dt_store(P.out, dt_index(P.out, mr, tt, bb), o);
+            o[i] = act_apply(P.act, total[t][i] * P.scale);
+            if (P.has_res) o[i] = (P.out32 ? o[i] : r16(o[i])) + (P.res32 ? __builtin_bit_cast(float, resb[t][i]) : (float)__builtin_bit_cast(f16, (uint16_t)resb[t][i]));
+        }
+        const size_t oo = (size_t)tok * P.os + m0 + 4 * g;
+        if (m0 + 4 * g + 4 <= P.m) {        // the common case: four consecutive rows in one store
+            if (P.out32) *(f32x4v*)((float*)P.out_p + oo) = (f32x4v){o[0], o[1], o[2], o[3]};
+            else { typedef _Float16 f16x4 __attribute__((ext_vector_type(4))); *(f16x4*)((f16*)P.out_p + oo) = (f16x4){(f16)o[0], (f16)o[1], (f16)o[2], (f16)o[3]}; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (m0 + 4 * g + i < P.m) { if (P.out32) ((float*)P.out_p)[oo + i] = o[i]; else ((f16*)P.out_p)[oo + i] = (f16)o[i]; }
         }
     }
     WRK_STAMP(P.dbg, 4);
@@ -858,8 +892,18 @@ uint32_t gemm_min_tokens() {
     return v;
 }
 
+// token tok = t + b * shape[1] of a [C, T, B] view sits at base + tok * stride[0] when the view covers the whole T extent of
+// its parent (or has a single batch)
+static bool dense_stack(const DTensor& d) { return d.shape[2] == 1 || (d.shape[1] == d.stride[1] && d.offset[1] == 0); }
+static size_t stack_base(const DTensor& d) { return ((size_t)d.offset[2] * d.stride[1] + d.offset[1]) * d.stride[0] + d.offset[0]; }
+
 static bool gemm_ok(const MatJob& j, uint32_t n) {
     if (j.in.shape[1] * j.in.shape[2] != n || n < gemm_min_tokens()) return false;
+    if (!dense_stack(j.in) || !dense_stack(j.out) || (j.has_res && !dense_stack(j.res))) return false;
+    if (j.m < 4 || (j.m & 3u) || (j.out.dtype != WRK_F16 && j.out.dtype != WRK_F32) || (j.has_res && j.res.dtype != WRK_F16 && j.res.dtype != WRK_F32)) return false;
+    // four consecutive output rows are stored (and residual rows loaded) as one vector
+    if (((stack_base(j.out) | j.out.stride[0]) & 3u) || (j.has_res && ((stack_base(j.res) | j.res.stride[0]) & 3u))) return false;
+    if (j.k < 32) return false;
     if (j.flags & WRK_MATRIX_ROUND_F16) return false;       // parity mode: per-element f16 rounding lives in the matvec kernels
     if (j.in.dtype != WRK_F16 || (j.k & 31u)) return false;
     // rows of the input views must be 16-byte aligned for the B-fragment loads
@@ -876,6 +920,11 @@ static bool gemm_ok(const MatJob& j, uint32_t n) {
 static void fill_job(GemmParams& P, const MatJob& j, uint32_t n, uint32_t wg_begin) {
     P.w = j.w; P.kind = j.kind; P.k = j.k; P.m = j.m; P.row_bytes = j.row_bytes; P.act = j.act; P.n = n;
     P.has_res = j.has_res; P.in = j.in; P.out = j.out; P.res = j.res; P.wg_begin = wg_begin; P.scale = j.scale; P.dbg = j.dbg;
+    P.x = (const f16*)j.in.p + stack_base(j.in); P.xs = j.in.stride[0];
+    P.out32 = j.out.dtype == WRK_F32; P.os = j.out.stride[0];
+    P.out_p = (char*)j.out.p + stack_base(j.out) * (P.out32 ? 4 : 2);
+    P.res32 = j.has_res && j.res.dtype == WRK_F32; P.rs = j.has_res ? j.res.stride[0] : 0;
+    P.res_p = j.has_res ? (const char*)j.res.p + stack_base(j.res) * (P.res32 ? 4 : 2) : nullptr;
 }
 
 int matmul_mfma_multi(hipStream_t s, const MatJob* jobs, int njobs, int) {
