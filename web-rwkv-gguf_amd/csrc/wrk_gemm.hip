@@ -752,6 +752,155 @@ __device__ __forceinline__ void gemm_tile_body_q6k(const GemmParams& P, f16* __r
     }
 }
 
+// ------------------------------------------------------------------ prefill tile kernel, second generation (Q4_K / Q5_K)
+// Round 2.  What bounded the first tile kernel (12-15 % of the dense f16 MFMA peak): (a) one dequantised 16 x 32 fragment fed only
+// TILE_TT = 4 MFMAs, so the VALU dequant (~35 instructions per 64-k step) cost as much issue time as the matrix work; (b) its
+// predicated loads (`more ? load : zero`) made the compiler wait vmcnt(0) in front of every LDS store, so nothing was in flight
+// across a block.  Here a workgroup owns 64 rows x 16*TT tokens with TT = 8 (128 tokens: a fragment feeds 8 MFMAs; TT = 4 when
+// the launch would otherwise have too few workgroups), the activations are staged per HALF block (128 k: 2 x 34 KB of LDS at TT = 8,
+// still two workgroups per CU, a barrier every 8*TT MFMAs per wave as before), every global load is unconditional (clamped
+// indices; dead tokens are never stored), and a half-stage issues the NEXT half's activation loads before its weights so the LDS
+// store waits with a counted vmcnt.
+constexpr int T2_KH = 128, T2_ROW = T2_KH + 8;      // staged k per half block; LDS row stride in f16 (+16 B: conflict-free fragment reads)
+
+template <int KIND, int TT>
+__device__ __forceinline__ void gemm_tile2_body(const GemmParams& P, f16* __restrict__ lds) {
+    constexpr int TOK = 16 * TT, NST = TOK * 16 / 256;       // tokens per workgroup; 16-byte chunks a thread stages per half block
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const uint32_t r = lane & 15, g = lane >> 4;
+    const uint32_t m0 = (blockIdx.x - P.wg_begin) * TILE_ROWS + wave * 16;     // this wave's 16 rows
+    const uint32_t n0 = blockIdx.y * TOK;
+    const uint32_t K = P.k, nb = K >> 8;
+    const uint8_t* wrow = P.w + (size_t)min(m0 + r, P.m - 1) * P.row_bytes;
+    const uint32_t hoff = KIND == WRK_MAT_Q4_K ? nb * 128 : nb * 160, soff = hoff + nb * 4;
+    const uint8_t* crow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) crow[i] = P.w + (size_t)min(m0 + 4 * g + i, P.m - 1) * P.row_bytes + hoff;
+
+    // staging: TOK tokens x 16 chunks of 8 f16 per half block; chunk q of a thread -> token (tid >> 4) + 16 q, columns 8 (tid & 15)
+    const f16* xsrc[NST];
+#pragma unroll
+    for (int q = 0; q < NST; ++q) xsrc[q] = P.x + (size_t)min(n0 + (tid >> 4) + 16 * q, P.n - 1) * P.xs + (tid & 15u) * 8;
+    f16x8 stage[NST];
+    const uint32_t nhalf = 2 * nb;
+    auto fetch_x = [&](uint32_t h) {            // half block h (clamped: the extra fetch after the last half is never stored)
+        const uint32_t hc = min(h, nhalf - 1);
+#pragma unroll
+        for (int q = 0; q < NST; ++q) stage[q] = *(const f16x8*)(xsrc[q] + (size_t)hc * T2_KH);
+    };
+    auto store_x = [&](uint32_t buf) {
+        f16* base = lds + (size_t)buf * TOK * T2_ROW;
+#pragma unroll
+        for (int q = 0; q < NST; ++q) *(f16x8*)(base + ((tid >> 4) + 16 * q) * T2_ROW + (tid & 15u) * 8) = stage[q];
+    };
+    struct WBlk { u32x2 q[4]; u32x2 qh; u32x4 sm; uint32_t dd[4]; };
+    auto load_w = [&](WBlk& R, uint32_t b0) {
+        const uint32_t b = min(b0, nb - 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) R.q[j] = *(const u32x2*)(wrow + (size_t)b * 128 + j * 32 + 8 * g);
+        if (KIND == WRK_MAT_Q5_K) R.qh = *(const u32x2*)(wrow + (size_t)nb * 128 + (size_t)b * 32 + 8 * g);
+        R.sm = *(const u32x4*)(wrow + soff + (size_t)b * 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) R.dd[i] = *(const uint32_t*)(crow[i] + (size_t)b * 4);
+    };
+
+    f32x4v total[TT], acc[TT], amin[TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) total[t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+
+    WBlk W0, W1;
+    fetch_x(0);
+    load_w(W0, 0);
+    store_x(0);
+    __syncthreads();
+    // one half block: j = 2 hf, 2 hf + 1 of block b out of LDS buffer `buf`
+    auto half = [&](uint32_t b, int hf, uint32_t buf, const WBlk& R, WBlk& Rn) {
+        fetch_x(2 * b + hf + 1);                    // next half's activations first, then (once per block) the next block's weights
+        if (hf == 0) load_w(Rn, b + 1);
+        const f16* xt = lds + (size_t)buf * TOK * T2_ROW + r * T2_ROW + 8 * g;
+        if (hf == 0) {
+#pragma unroll
+            for (int t = 0; t < TT; ++t) { acc[t] = (f32x4v){0.f, 0.f, 0.f, 0.f}; amin[t] = (f32x4v){0.f, 0.f, 0.f, 0.f}; }
+        }
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int j = 2 * hf + jj;
+            const u32x2 q = R.q[j];
+            const uint32_t v = R.sm[j];
+            const float sc0 = (float)(v & 0xffu), sc1 = (float)((v >> 8) & 0xffu);
+            f16x8 alo, ahi;
+            if (KIND == WRK_MAT_Q4_K) {
+                alo = mul8(codes8(q.x & 0x0f0f0f0fu, q.y & 0x0f0f0f0fu), sc0 * 1024.0f);
+                ahi = mul8(codes8(q.x & 0xf0f0f0f0u, q.y & 0xf0f0f0f0u), sc1 * 64.0f);
+            } else {
+                const uint32_t s0 = 2 * j, s1 = 2 * j + 1;
+                alo = mul8(codes8((q.x & 0x0f0f0f0fu) | (((R.qh.x >> s0) & 0x01010101u) << 4), (q.y & 0x0f0f0f0fu) | (((R.qh.y >> s0) & 0x01010101u) << 4)), sc0 * 1024.0f);
+                ahi = mul8(codes8(((q.x >> 4) & 0x0f0f0f0fu) | (((R.qh.x >> s1) & 0x01010101u) << 4), ((q.y >> 4) & 0x0f0f0f0fu) | (((R.qh.y >> s1) & 0x01010101u) << 4)), sc1 * 1024.0f);
+            }
+            const f16 m0h = (f16)(float)((v >> 16) & 0xffu), m1h = (f16)(float)(v >> 24);
+            const f16x8 mlo = {m0h, m0h, m0h, m0h, m0h, m0h, m0h, m0h}, mhi = {m1h, m1h, m1h, m1h, m1h, m1h, m1h, m1h};
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+                const f16x8 b0 = *(const f16x8*)(xt + (size_t)t * 16 * T2_ROW + jj * 64);
+                const f16x8 b1 = *(const f16x8*)(xt + (size_t)t * 16 * T2_ROW + jj * 64 + 32);
+                acc[t] = mfma16(alo, b0, acc[t]);
+                acc[t] = mfma16(ahi, b1, acc[t]);
+                amin[t] = mfma16(mlo, b0, amin[t]);
+                amin[t] = mfma16(mhi, b1, amin[t]);
+            }
+        }
+        if (hf == 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float d = (float)__builtin_bit_cast(f16, (uint16_t)(R.dd[i] & 0xffffu)) * 16384.0f;
+                const float dmin = (float)__builtin_bit_cast(f16, (uint16_t)(R.dd[i] >> 16));
+#pragma unroll
+                for (int t = 0; t < TT; ++t) total[t][i] += d * acc[t][i] - dmin * amin[t][i];
+            }
+        }
+        store_x(buf ^ 1u);          // the other buffer was last read one half ago (the barrier below orders it)
+        __syncthreads();
+    };
+    for (uint32_t b = 0; b < nb; b += 2) {          // uniform over the workgroup
+        half(b, 0, 0u, W0, W1);
+        half(b, 1, 1u, W0, W1);
+        if (b + 1 >= nb) break;
+        half(b + 1, 0, 0u, W1, W0);
+        half(b + 1, 1, 1u, W1, W0);
+    }
+
+    // store: lane owns rows m0 + 4g + (0..3) of token column r of each 16-token tile (four consecutive rows: one vector)
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        const uint32_t tok = n0 + 16 * t + r;
+        if (tok >= P.n || m0 + 4 * g >= P.m) continue;
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = act_apply(P.act, total[t][i] * P.scale);
+        const size_t oo = (size_t)tok * P.os + m0 + 4 * g;
+        if (P.has_res) {
+            const size_t ro = (size_t)tok * P.rs + m0 + 4 * g;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = (P.out32 ? o[i] : r16(o[i])) + (P.res32 ? ((const float*)P.res_p)[ro + i] : (float)((const f16*)P.res_p)[ro + i]);
+        }
+        if (P.out32) *(f32x4v*)((float*)P.out_p + oo) = (f32x4v){o[0], o[1], o[2], o[3]};
+        else { typedef _Float16 f16x4 __attribute__((ext_vector_type(4))); *(f16x4*)((f16*)P.out_p + oo) = (f16x4){(f16)o[0], (f16)o[1], (f16)o[2], (f16)o[3]}; }
+    }
+}
+
+template <int TT>
+__global__ void __launch_bounds__(256) gemm_tile2_kernel(const GemmBatch B) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char tile2_smem[];
+    int ji = 0;
+#pragma unroll
+    for (int q = 1; q < GEMM_MAX_JOBS; ++q)
+        if (q < B.njobs && blockIdx.x >= B.jobs[q].wg_begin) ji = q;
+    const GemmParams& P = B.jobs[ji];
+    if (P.kind == WRK_MAT_Q4_K) gemm_tile2_body<WRK_MAT_Q4_K, TT>(P, (f16*)tile2_smem);
+    else gemm_tile2_body<WRK_MAT_Q5_K, TT>(P, (f16*)tile2_smem);
+}
+
 __global__ void __launch_bounds__(256) gemm_tile_kernel(const GemmBatch B) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tile_smem[];
     int ji = 0;
@@ -938,9 +1087,10 @@ int matmul_mfma_multi(hipStream_t s, const MatJob* jobs, int njobs, int) {
     // measured (round 1): SLOWER than the K-split kernel -- 12.2 vs 8.9 us for 8192 x 2048 x 16 tokens, batch-16 decode 2.35 vs
     // 1.76 ms -- 128 workgroups leave half the CUs idle and every 256-block costs a workgroup barrier.  Off unless WRK_GEMM_DEC=1.
     static const bool use_dec = [] { const char* e = getenv("WRK_GEMM_DEC"); return e && e[0] == '1'; }();
-    GemmBatch T, B, Dq;
-    T.njobs = B.njobs = Dq.njobs = 0;
-    uint32_t twg = 0, wg = 0, kmax = 0, dwg = 0;
+    GemmBatch T, B, Dq, T2;
+    T.njobs = B.njobs = Dq.njobs = T2.njobs = 0;
+    uint32_t twg = 0, wg = 0, kmax = 0, dwg = 0, t2wg = 0;
+    static const bool use_tile2 = [] { const char* e = getenv("WRK_GEMM_TILE2"); return !(e && e[0] == '0'); }();
     for (int q = 0; q < njobs; ++q) {
         const MatJob& j = jobs[q];
         // decode batches (<= 16 tokens): rows up to 24 blocks long go to the 64-row LDS tile; longer rows keep the K split
@@ -956,8 +1106,24 @@ int matmul_mfma_multi(hipStream_t s, const MatJob* jobs, int njobs, int) {
                           j.in.shape[2] == 1 && (tiles >= 96 || (j.k <= 2560 && tiles >= 64) ||    // enough workgroups, or a short serial walk,
                                                  (j.kind == WRK_MAT_F16 && j.k <= 2560));          // or a LoRA down-projection (64..320 rows): a handful of
         // tiles that ride along with the big matrices of their stage; on the K-split kernel they were a 32-us launch of 64 workgroups per layer
-        if (tile) { fill_job(T.jobs[T.njobs++], j, n, twg); twg += (j.m + TILE_ROWS - 1) / TILE_ROWS; }
+        // K4 kinds whose output rows come in fours (one vector store per lane) take the second-generation tile kernel
+        // (with few workgroups -- a single 128-token chunk -- the first-generation kernel's longer stages are 4 % faster)
+        if (tile && use_tile2 && n >= 512 && (j.kind == WRK_MAT_Q4_K || j.kind == WRK_MAT_Q5_K) && (j.m & 3u) == 0) { fill_job(T2.jobs[T2.njobs++], j, n, t2wg); t2wg += (j.m + TILE_ROWS - 1) / TILE_ROWS; }
+        else if (tile) { fill_job(T.jobs[T.njobs++], j, n, twg); twg += (j.m + TILE_ROWS - 1) / TILE_ROWS; }
         else { fill_job(B.jobs[B.njobs++], j, n, wg); wg += (j.m + 15) / 16; kmax = j.k > kmax ? j.k : kmax; }
+    }
+    if (T2.njobs) {
+        // 64-token tiles (TT = 4).  Measured on MI355X (round 2, 32 x 128-token prefill, tokens/s, 1.5B | 2.9B): first-generation tile
+        // 86.8 k | 44.1 k; this kernel TT = 4 96.2 k | 49.0 k, TT = 6 96.8 k | 48.6 k, TT = 8 83.3 k | 42.1 k (308 registers: one
+        // workgroup per CU, or spills at 256) -- more MFMAs per dequantised fragment buy nothing, the LDS fragment reads (1 KB per two
+        // MFMAs) are the co-limiter; the gain is the unconditional loads and the shorter stages.
+        const size_t smem2 = (size_t)2 * 64 * T2_ROW * sizeof(f16);       // 34 816 B
+        static bool done = false;
+        if (!done) {
+            if (hipFuncSetAttribute((const void*)gemm_tile2_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2) != hipSuccess) return -1;
+            done = true;
+        }
+        gemm_tile2_kernel<4><<<dim3(t2wg, (n + 63) / 64), 256, smem2, s>>>(T2);
     }
     if (T.njobs) {
         const size_t smem = (size_t)2 * TILE_TOK * TILE_LDS_ROW * sizeof(f16);       // 67 584 B
