@@ -62,6 +62,14 @@ int32_t wrk_gguf_info(const wrk_gguf* g, wrk_model_info* out);
  * feed it to wrk_v7_state_load.  WRK_E_ARG when the file has no time_state tensors. */
 int32_t wrk_gguf_read_state(const wrk_gguf* g, float* out, size_t capacity, size_t* count);
 
+/* quantile_student (src/tensor/matrix.rs:29-44) = the 16 levels of Float4Quant::new_student(nu) ("SF4"; nu = 5 for most cases):
+ * Student-t quantiles at p = delta + i (0.5 - delta) / 7 (i = 0..6) and 0.5 + i (0.5 - delta) / 8 (i = 0..8) with
+ * delta = (1/32 + 1/30) / 2, divided by the largest.  The reference takes the inverse CDF from the un-vendored statrs 0.18.0
+ * (Cargo.toml:51); here it is the root of the t CDF (regularised incomplete beta, continued fraction) refined by Newton steps in
+ * f64 -- PARITY UNPINNED against statrs, pinned against scipy.stats.t.ppf to 1e-6 in tests/test_abi_host.py.
+ * Pass the result to wrk_matrix_quantize(WRK_MAT_NF4, ..., levels) for Matrix::quant_sf4 (matrix.rs:251-271). */
+int32_t wrk_quantile_student(double nu, float* out16);
+
 /* ------------------------------------------------------------ RnnInput / RnnIter */
 enum { WRK_RNN_NONE = -1, WRK_RNN_LAST = 0, WRK_RNN_FULL = 1 };
 

@@ -88,8 +88,21 @@ for _v in ("x_r", "x_w", "x_k", "x_v", "x_a", "x_g"):
 _FUSED_SUFFIX = [(".att.x_r", 0), (".att.x_w", 1), (".att.x_k", 2), (".att.x_v", 3), (".att.x_a", 4), (".att.x_g", 5)]
 
 
-def gguf_to_safetensors_name(name: str) -> Optional[str]:
-    """gguf.rs:1173-1329."""
+# llama.cpp's RWKV-6 names, as the reference's own converter emits them (assets/scripts/convert_hf_to_gguf.py:455-525); the
+# reference's map lacks them (gguf.rs:1212-1229) and maps time_mix_w1.weight to the V7 tensor (gguf.rs:1261): SURVEY H6.
+# Applied when general.architecture == "rwkv6", before the shared rules.  Parity unpinned (gguf-py absent).
+_BLK_V6 = {
+    "time_mix_lerp_x.weight": "att.time_mix_x", "time_mix_lerp_w.weight": "att.time_mix_w", "time_mix_lerp_k.weight": "att.time_mix_k",
+    "time_mix_lerp_v.weight": "att.time_mix_v", "time_mix_lerp_r.weight": "att.time_mix_r", "time_mix_lerp_g.weight": "att.time_mix_g",
+    "time_mix_w1.weight": "att.time_mix_w1", "time_mix_w2.weight": "att.time_mix_w2",
+    "time_mix_decay.weight": "att.time_decay", "time_mix_decay_w1.weight": "att.time_decay_w1", "time_mix_decay_w2.weight": "att.time_decay_w2",
+    "time_mix_first.weight": "att.time_first",
+    "channel_mix_lerp_k.weight": "ffn.time_mix_k", "channel_mix_lerp_r.weight": "ffn.time_mix_r",
+}
+
+
+def gguf_to_safetensors_name(name: str, arch_v6: bool = False) -> Optional[str]:
+    """gguf.rs:1173-1329 (+ the llama.cpp RWKV-6 names when the file says rwkv6)."""
     if name in _TOP:
         return _TOP[name]
     if name.startswith("blk."):
@@ -97,6 +110,8 @@ def gguf_to_safetensors_name(name: str) -> Optional[str]:
         dot = rest.find(".")
         if dot >= 0:
             blk, rem = rest[:dot], rest[dot + 1:]
+            if arch_v6 and rem in _BLK_V6:
+                return f"blocks.{blk}.{_BLK_V6[rem]}"
             if rem in _BLK:
                 return f"blocks.{blk}.{_BLK[rem]}"
     return None
@@ -190,8 +205,9 @@ class GgufReader:
             self.tensors[name] = TensorInfo(name, dims, t, off)
         self.tensor_data_offset = align_offset(c.pos, alignment)
         self.name_map: Dict[str, str] = {}
+        arch_v6 = self.metadata.get("general.architecture") == "rwkv6"
         for g in self.tensors:                    # build_rwkv_name_map, gguf.rs:1160-1171
-            s = gguf_to_safetensors_name(g)
+            s = gguf_to_safetensors_name(g, arch_v6)
             if s is not None:
                 self.name_map[s] = g
             self.name_map[g] = g

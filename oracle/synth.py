@@ -226,11 +226,29 @@ def v6_tensor_plan(cfg: V6Config, seed: int):
         yield p + "ffn_r.weight", [D, D], "mat", N(k + "ffn.rec", D * D, 1.0 / np.sqrt(D))
 
 
+# attn_* / ffn_* spelling (what the reference's map knows) -> llama.cpp's RWKV-6 spelling (what its own converter emits,
+# assets/scripts/convert_hf_to_gguf.py:455-525); same dims and data
+_V6_LLAMA = {"attn_time_decay": "time_mix_decay.weight", "attn_time_first": "time_mix_first.weight",
+             "attn_time_mix_x": "time_mix_lerp_x.weight", "attn_time_mix_w": "time_mix_lerp_w.weight", "attn_time_mix_k": "time_mix_lerp_k.weight",
+             "attn_time_mix_v": "time_mix_lerp_v.weight", "attn_time_mix_r": "time_mix_lerp_r.weight", "attn_time_mix_g": "time_mix_lerp_g.weight",
+             "attn_time_mix_w1": "time_mix_w1.weight", "attn_time_mix_w2": "time_mix_w2.weight",
+             "attn_time_decay_w1": "time_mix_decay_w1.weight", "attn_time_decay_w2": "time_mix_decay_w2.weight",
+             "attn_ln_x.weight": "time_mix_ln.weight", "attn_ln_x.bias": "time_mix_ln.bias",
+             "attn_k.weight": "time_mix_key.weight", "attn_v.weight": "time_mix_value.weight", "attn_r.weight": "time_mix_receptance.weight",
+             "attn_g.weight": "time_mix_gate.weight", "attn_output.weight": "time_mix_output.weight",
+             "ffn_time_mix_k": "channel_mix_lerp_k.weight", "ffn_time_mix_r": "channel_mix_lerp_r.weight",
+             "ffn_k.weight": "channel_mix_key.weight", "ffn_v.weight": "channel_mix_value.weight", "ffn_r.weight": "channel_mix_receptance.weight"}
+
+
 def make_v6_gguf(cfg: V6Config, seed: int = 42, mat: str = "Q5_K", head: str = "Q6_K", emb: str = "F16", lora: str = "F32",
-                 vec: str = "F32", mat_override: Dict[str, str] | None = None) -> bytes:
+                 vec: str = "F32", mat_override: Dict[str, str] | None = None, names: str = "attn") -> bytes:
+    """names: "attn" = the spellings the reference's map knows; "llama" = llama.cpp's RWKV-6 tensor names."""
     kinds = {"mat": mat, "head": head, "emb": emb, "lora": lora, "vec": vec}
     tensors = []
     for name, dims, kind, vals in v6_tensor_plan(cfg, seed):
+        if names == "llama" and name.startswith("blk."):
+            pre, rem = name.split(".", 2)[:2], name.split(".", 2)[2]
+            name = ".".join(pre) + "." + _V6_LLAMA.get(rem, rem)
         tn = kinds[kind]
         if mat_override and kind == "mat":
             for sub, t in mat_override.items():

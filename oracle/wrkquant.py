@@ -91,3 +91,13 @@ def repack_q4_0_to_nf4(data: np.ndarray, num_elements: int):
     x = v * inv[:, None]
     idx = np.argmin(np.abs(NF4_LEVELS[None, None, :] - x[:, :, None]), axis=2).astype(np.uint8).reshape(-1)
     return (idx[0::2] | (idx[1::2] << 4)).astype(np.uint8), amax.astype(np.float16)
+
+
+def quantile_student(nu: float) -> np.ndarray:
+    """quantile_student (matrix.rs:29-44): Student-t quantiles (scipy.stats.t.ppf stands in for statrs 0.18's inverse_cdf) at the
+    reference's 16 probabilities, normalised by the largest; f32 like the reference's Vec<f32>."""
+    from scipy.stats import t as student
+    delta = (1.0 / 32.0 + 1.0 / 30.0) / 2.0
+    p = [delta + (0.5 - delta) / 7.0 * i for i in range(7)] + [0.5 + (1.0 - delta - 0.5) / 8.0 * i for i in range(9)]
+    q = student.ppf(np.asarray(p, np.float64), nu)
+    return (q / q.max()).astype(np.float32)

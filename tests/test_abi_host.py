@@ -153,6 +153,35 @@ def test_chunk_size_rounding():
     assert _inp([(1, L)], 1).token_chunk_size == 32 and _inp([(1, L)], 33).token_chunk_size == 64
 
 
+def test_llama_cpp_rwkv6_names_load_like_the_attn_spellings():
+    """a llama.cpp RWKV-6 file (time_mix_lerp_*, time_mix_decay*, time_mix_w1/w2 ..., general.architecture rwkv6)
+    resolves to the same safetensors names, shapes and values as the attn_* spelling, in the C++ host and in the oracle; the V7
+    meaning of time_mix_w1.weight (att.w1) is untouched for rwkv7 files."""
+    from oracle import rwkv6 as orwkv6
+    cfg = synth.V6_CONFIGS["tiny"]
+    a, b = synth.make_v6_gguf(cfg, 42), synth.make_v6_gguf(cfg, 42, names="llama")
+    assert a != b
+    ra, rb, oa, ob = wrk.GgufReader(a), wrk.GgufReader(b), ogguf.GgufReader(a), ogguf.GgufReader(b)
+    names = ["att.time_mix_x", "att.time_mix_w", "att.time_mix_g", "att.time_mix_w1", "att.time_mix_w2", "att.time_decay", "att.time_decay_w1",
+             "att.time_decay_w2", "att.time_first", "att.key.weight", "att.gate.weight", "att.output.weight", "att.ln_x.bias",
+             "ffn.time_mix_k", "ffn.time_mix_r", "ffn.key.weight", "ffn.value.weight", "ffn.receptance.weight"]
+    for n in names:
+        for layer in (0, 1):
+            full = f"blocks.{layer}.{n}"
+            assert rb.contains(full) and ob.contains(full), full
+            assert rb.shape(full) == ra.shape(full) == ob.shape(full) == oa.shape(full), full
+            assert np.array_equal(rb.tensor_f16(full), ra.tensor_f16(full)), full
+            assert np.array_equal(ob.tensor(full)[2], oa.tensor(full)[2]), full
+    ia, ib = ra.info(), rb.info()
+    assert (ib.version, ib.num_layer, ib.num_emb, ib.num_hidden, ib.num_vocab, ib.num_head, ib.lora_w, ib.lora_a) == \
+           (ia.version, ia.num_layer, ia.num_emb, ia.num_hidden, ia.num_vocab, ia.num_head, ia.lora_w, ia.lora_a) and ib.version == 6
+    mb = orwkv6.loader_info_v6(ob)
+    assert mb.custom == orwkv6.loader_info_v6(oa).custom
+    # in an rwkv7 file the shared spellings keep their V7 meaning (gguf.rs:1253-1271)
+    v7 = wrk.GgufReader(synth.make_v7_gguf(synth.CONFIGS["tiny"], 42))
+    assert v7.contains("blocks.1.att.w1") and not v7.contains("blocks.1.att.time_mix_w1")
+
+
 def test_host_v6_info_and_tensors_match_oracle():
     from oracle import rwkv6
     data = synth.make_v6_gguf(synth.V6_CONFIGS["tiny"], 42)
@@ -204,3 +233,15 @@ def test_read_state_matches_oracle():
     assert got[l, 1 + j, h * S + c] == np.float32(np.float16(ts[l][h, j, c]))
     with pytest.raises(wrk.WrkError):
         wrk.GgufReader(synth.make_v7_gguf(cfg, 5)).read_state()      # no time_state tensors in a plain model
+
+
+def test_quantile_student_levels():
+    """Float4Quant::new_student (matrix.rs:29-44): 16 monotone levels in [-1, 1], 0 at index 7, equal to the oracle's (scipy) values."""
+    from oracle import wrkquant
+    for nu in (5.0, 3.0, 30.0):
+        got, want = wrk.quantile_student(nu), wrkquant.quantile_student(nu)
+        assert got.shape == (16,) and got[7] == 0.0 and got[15] == 1.0 and np.all(np.diff(got) > 0)
+        assert abs(got[0] + 1.0) < 1e-6                              # p[0] = delta and p[15] = 1 - delta are symmetric
+        assert np.allclose(got, want, rtol=1e-6, atol=1e-7), (nu, np.abs(got - want).max())
+    with pytest.raises(wrk.WrkError):
+        wrk.quantile_student(-1.0)

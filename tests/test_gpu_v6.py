@@ -187,3 +187,20 @@ def test_v6_merged_prefill_launches_are_bit_identical_to_the_op_list(ctx):
     for x, y in zip(out[0][0], out[1][0]):
         assert np.array_equal(x, y), float(np.abs(x - y).max())
     assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+
+
+def test_llama_cpp_tensor_names_run_identically(ctx):
+    """BASELINE cfg 4 / 5 files come from llama.cpp's converter (time_mix_lerp_*, time_mix_decay*, ...): the same weights under those
+    names must produce bit-identical logits and state (tests/test_abi_host.py checks the name resolution itself)."""
+    cfg = synth.V6_CONFIGS["tiny"]
+    V = cfg.num_vocab
+    p = synth.tokens(21, "llama-names", 37, V)
+    out = []
+    for names in ("attn", "llama"):
+        rt = wrk.Runtime(ctx, wrk.GgufReader(synth.make_v6_gguf(cfg, 42, names=names)), num_batch=1)
+        a = rt.infer(wrk.RnnInput([p], 64), mode=1)[0]
+        t, _, l = rt.generate_greedy([int(a[0].argmax())], 6, mode=1, want_logits=True)
+        out.append((a, t, l, rt.state_back(0)))
+        rt.close()
+    for x, y in zip(out[0], out[1]):
+        assert np.array_equal(x, y)

@@ -77,11 +77,17 @@ def test_quant_nf4_codes_and_absmax(ctx, k, m):
     assert mat.stream_bytes == n // 2 + n // 64 * 2
 
 
-def test_quant_sf4_levels(ctx):
-    """quant_sf4 uses the same kernel with the caller's level table (Float4Quant::new_student)."""
+@pytest.mark.parametrize("student", [False, True])
+def test_quant_sf4_levels(ctx, student):
+    """quant_sf4 uses the same kernel with the caller's level table: Float4Quant::new_student(5.0) from the host's
+    quantile_student (matrix.rs:29-44, 251-271), or any other 16 levels."""
     k, m = 256, 16
-    levels = np.sort(np.tanh(np.linspace(-2.0, 2.0, 16))).astype(np.float32)
-    levels /= levels.max()
+    if student:
+        levels = wrk.quantile_student(5.0)
+        assert np.allclose(levels, wq.quantile_student(5.0), rtol=1e-6, atol=1e-7)
+    else:
+        levels = np.sort(np.tanh(np.linspace(-2.0, 2.0, 16))).astype(np.float32)
+        levels /= levels.max()
     w = weights(k, m, 9)
     mat = wrk.Matrix.quant_sf4(wrk.Buffer(ctx, w.nbytes, w), k, m, levels)
     blob = mat.export()

@@ -322,16 +322,32 @@ const Pair BLK[] = {
     {"time_mix_receptance.weight", "att.receptance.weight"}, {"time_mix_gate.weight", "att.gate.weight"},
     {"time_mix_output.weight", "att.output.weight"}, {"time_mix_lerp_fused.weight", "att.time_maa"},
     {"time_mix_ln.weight", "att.ln_x.weight"}, {"time_mix_ln.bias", "att.ln_x.bias"}, {"ffn_x_k", "ffn.x_k"}};
+// llama.cpp's RWKV-6 tensor names (the ones the reference's own assets/scripts/convert_hf_to_gguf.py:455-525 emits through
+// gguf-py's MODEL_ARCH.RWKV6 table).  The reference's map (gguf.rs:1212-1229) only knows the attn_time_* / time_maa_* spellings and
+// sends `time_mix_w1.weight` to the RWKV-7 tensor att.w1 (gguf.rs:1261) -- SURVEY H6 -- so a real llama.cpp RWKV-6 file does not
+// load there.  This table applies when general.architecture == "rwkv6" and takes precedence over the V7 rules for the names both
+// families use (time_mix_w1 / w2, channel_mix_lerp_k).  Layouts need no change: the converter's transposes give exactly the dims
+// the attn_* spellings carry ([D, 5R], [R, D, 5], [D, W], [W, D], [S, H]).  PARITY UNPINNED: gguf-py is not in this image; the
+// names are pinned only by that converter script.
+const Pair BLK_V6[] = {
+    {"time_mix_lerp_x.weight", "att.time_mix_x"}, {"time_mix_lerp_w.weight", "att.time_mix_w"}, {"time_mix_lerp_k.weight", "att.time_mix_k"},
+    {"time_mix_lerp_v.weight", "att.time_mix_v"}, {"time_mix_lerp_r.weight", "att.time_mix_r"}, {"time_mix_lerp_g.weight", "att.time_mix_g"},
+    {"time_mix_w1.weight", "att.time_mix_w1"}, {"time_mix_w2.weight", "att.time_mix_w2"},
+    {"time_mix_decay.weight", "att.time_decay"}, {"time_mix_decay_w1.weight", "att.time_decay_w1"}, {"time_mix_decay_w2.weight", "att.time_decay_w2"},
+    {"time_mix_first.weight", "att.time_first"},
+    {"channel_mix_lerp_k.weight", "ffn.time_mix_k"}, {"channel_mix_lerp_r.weight", "ffn.time_mix_r"}};
 const char* V7_SHORT[] = {"w0", "w1", "w2", "a0", "a1", "a2", "g1", "g2", "v0", "v1", "v2", "r_k", "k_k", "k_a"};
 const char* V7_LERP[] = {"x_r", "x_w", "x_k", "x_v", "x_a", "x_g"};
 
-bool gguf_to_safetensors_name(const std::string& g, std::string& out) {
+bool gguf_to_safetensors_name(const std::string& g, std::string& out, bool arch_v6 = false) {
     for (const Pair& p : TOP) if (g == p.gguf) { out = p.st; return true; }
     if (g.rfind("blk.", 0) != 0) return false;
     const std::string rest = g.substr(4);
     const size_t dot = rest.find('.');
     if (dot == std::string::npos) return false;
     const std::string blk = rest.substr(0, dot), rem = rest.substr(dot + 1);
+    if (arch_v6)
+        for (const Pair& p : BLK_V6) if (rem == p.gguf) { out = "blocks." + blk + "." + p.st; return true; }
     for (const Pair& p : BLK) if (rem == p.gguf) { out = "blocks." + blk + "." + p.st; return true; }
     for (const char* s : V7_SHORT) {
         const std::string v(s);
@@ -456,9 +472,14 @@ struct wrk_gguf {
             tensors[ti.name] = ti;
         }
         tensor_data_offset = pos + (alignment - (pos % alignment)) % alignment;      // align_offset, gguf.rs:1415-1417
+        bool arch_v6 = false;
+        {
+            auto ar = metadata.find("general.architecture");
+            arch_v6 = ar != metadata.end() && ar->second.kind == 5 && ar->second.s == "rwkv6";
+        }
         for (const std::string& g : order) {                                         // build_rwkv_name_map
             std::string st;
-            if (gguf_to_safetensors_name(g, st)) name_map[st] = g;
+            if (gguf_to_safetensors_name(g, st, arch_v6)) name_map[st] = g;
             name_map[g] = g;
         }
         // every tensor must lie inside the file: the loader hands these pointers to the device
@@ -876,6 +897,76 @@ int32_t wrk_rnn_redirect(const uint32_t* lens, const int32_t* options, uint32_t 
         if (inputs) { inputs[2 * b] = i[b].first; inputs[2 * b + 1] = i[b].second; }
         if (outputs) { outputs[2 * b] = o[b].first; outputs[2 * b + 1] = o[b].second; }
     }
+    return WRK_OK;
+}
+
+// ---------------------------------------------------------------- quantile_student (matrix.rs:29-44)
+namespace {
+// regularised incomplete beta I_x(a, b) by Lentz's continued fraction (f64)
+double betacf(double a, double b, double x) {
+    const double tiny = 1e-300;
+    double qab = a + b, qap = a + 1.0, qam = a - 1.0, c = 1.0, d = 1.0 - qab * x / qap;
+    if (std::fabs(d) < tiny) d = tiny;
+    d = 1.0 / d;
+    double h = d;
+    for (int m = 1; m <= 500; ++m) {
+        const double m2 = 2.0 * m;
+        double aa = m * (b - m) * x / ((qam + m2) * (a + m2));
+        d = 1.0 + aa * d; if (std::fabs(d) < tiny) d = tiny;
+        c = 1.0 + aa / c; if (std::fabs(c) < tiny) c = tiny;
+        d = 1.0 / d; h *= d * c;
+        aa = -(a + m) * (qab + m) * x / ((a + m2) * (qap + m2));
+        d = 1.0 + aa * d; if (std::fabs(d) < tiny) d = tiny;
+        c = 1.0 + aa / c; if (std::fabs(c) < tiny) c = tiny;
+        d = 1.0 / d;
+        const double del = d * c;
+        h *= del;
+        if (std::fabs(del - 1.0) < 1e-16) break;
+    }
+    return h;
+}
+double betai(double a, double b, double x) {
+    if (x <= 0.0) return 0.0;
+    if (x >= 1.0) return 1.0;
+    const double bt = std::exp(std::lgamma(a + b) - std::lgamma(a) - std::lgamma(b) + a * std::log(x) + b * std::log1p(-x));
+    return x < (a + 1.0) / (a + b + 2.0) ? bt * betacf(a, b, x) / a : 1.0 - bt * betacf(b, a, 1.0 - x) / b;
+}
+double student_cdf(double t, double nu) {
+    const double tail = 0.5 * betai(0.5 * nu, 0.5, nu / (nu + t * t));
+    return t >= 0.0 ? 1.0 - tail : tail;
+}
+double student_pdf(double t, double nu) {
+    return std::exp(std::lgamma(0.5 * (nu + 1.0)) - std::lgamma(0.5 * nu) - 0.5 * std::log(nu * M_PI) - 0.5 * (nu + 1.0) * std::log1p(t * t / nu));
+}
+double student_inv_cdf(double p, double nu) {
+    if (p == 0.5) return 0.0;
+    double lo = -1.0, hi = 1.0;
+    while (student_cdf(lo, nu) > p) lo *= 2.0;
+    while (student_cdf(hi, nu) < p) hi *= 2.0;
+    for (int i = 0; i < 200 && hi - lo > 1e-15 * std::max(1.0, std::fabs(lo)); ++i) {      // bisection to the last bits ...
+        const double mid = 0.5 * (lo + hi);
+        if (student_cdf(mid, nu) < p) lo = mid; else hi = mid;
+    }
+    double t = 0.5 * (lo + hi);
+    for (int i = 0; i < 3; ++i) {                                                           // ... polished by Newton steps
+        const double f = student_cdf(t, nu) - p, g = student_pdf(t, nu);
+        if (g > 0.0 && std::isfinite(f / g)) t -= f / g;
+    }
+    return t;
+}
+}  // namespace
+
+int32_t wrk_quantile_student(double nu, float* out16) {
+    if (!out16 || !(nu > 0.0) || !std::isfinite(nu)) return fail(WRK_E_ARG, "quantile_student: nu must be positive and finite");
+    const double delta = (1.0 / 32.0 + 1.0 / 30.0) / 2.0;
+    double p[16], q[16];
+    double step = (0.5 - delta) / 7.0;
+    for (int i = 0; i < 7; ++i) p[i] = delta + step * i;
+    step = (1.0 - delta - 0.5) / 8.0;
+    for (int i = 0; i < 9; ++i) p[7 + i] = 0.5 + step * i;
+    double mx = -1e300;
+    for (int i = 0; i < 16; ++i) { q[i] = student_inv_cdf(p[i], nu); mx = std::max(mx, q[i]); }
+    for (int i = 0; i < 16; ++i) out16[i] = (float)(q[i] / mx);
     return WRK_OK;
 }
 

@@ -151,6 +151,7 @@ RT_SYMBOLS = {
     "wrk_gguf_meta_u64": (C.c_int32, [_P, C.c_char_p, C.POINTER(C.c_uint64)]),
     "wrk_gguf_read_state": (C.c_int32, [_P, _f32p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "wrk_gguf_info": (C.c_int32, [_P, C.POINTER(ModelInfo)]),
+    "wrk_quantile_student": (C.c_int32, [C.c_double, _f32p]),
     "wrk_rnn_input_create": (C.c_int32, [C.c_uint32, C.c_uint32, C.POINTER(_P)]),
     "wrk_rnn_input_destroy": (C.c_int32, [_P]),
     "wrk_rnn_input_token_chunk_size": (C.c_uint32, [_P]),
@@ -494,6 +495,13 @@ class TensorOp:
 def _host_check(rc: int):
     if rc != OK:
         raise WrkError(rc, (rt.wrk_host_last_error() or b"").decode())
+
+
+def quantile_student(nu: float = 5.0) -> np.ndarray:
+    """`quantile_student(nu)` (src/tensor/matrix.rs:29-44): the 16 f32 levels of `Float4Quant::new_student(nu)` (SF4)."""
+    out = np.zeros(16, np.float32)
+    _host_check(rt.wrk_quantile_student(float(nu), _ptr(out, _f32p)))
+    return out
 
 
 class GgufReader:
