@@ -194,7 +194,7 @@ def test_llama_cpp_tensor_names_run_identically(ctx):
     names must produce bit-identical logits and state (tests/test_abi_host.py checks the name resolution itself)."""
     cfg = synth.V6_CONFIGS["tiny"]
     V = cfg.num_vocab
-    p = synth.tokens(21, "llama-names", 37, V)
+    p = synth.tokens(21, "llama-names", 32, V)        # one 32-token chunk
     out = []
     for names in ("attn", "llama"):
         rt = wrk.Runtime(ctx, wrk.GgufReader(synth.make_v6_gguf(cfg, 42, names=names)), num_batch=1)

@@ -73,6 +73,7 @@ struct GemmParams {
     // dense token stacks for the K-split kernel: token tok at base + tok * stride (elements)
     const f16* x; const void* res_p; void* out_p;
     uint32_t xs, rs, os, out32, res32;
+    const float* levels;        // NF4 / SF4: the 16 f32 levels (device)
 };
 
 constexpr int GEMM_MAX_JOBS = 8;
@@ -223,6 +224,61 @@ __device__ __forceinline__ void gemm_body(const GemmParams& P, float (*sh_tot)[N
                 for (int t = 0; t < NT; ++t) total[t][i] += sc * acc[t][i] + mn * asum[t][i];
             }
         }
+    } else if (KIND == WRK_MAT_NF4) {
+        // web-rwkv NF4 / SF4 (matmul_mat_nf4, ops.rs:1150-1222): w = level[q] * absmax per 64 elements, levels = 16 f32 of Matrix::Fp4 { q }.
+        // The levels are not integers, so each goes through the matrix core as hi + lo with hi = f16(level), lo = f16(level - hi): two
+        // MFMAs per 32-k step, products exact, level error 2^-22 relative; absmax is applied to the f32 sum per 64-block.  The (hi, lo)
+        // pairs sit in LDS (one dword per level); a lane looks up its 8 nibbles per step.
+        uint32_t* lut = (uint32_t*)&sh_tot[0][0][0][0] + (NW - 1) * NT * 4 * 64;       // 16 dwords behind the K-split partials
+        if (threadIdx.x < 16) {
+            const float lv = P.levels[threadIdx.x];
+            const f16 hi = (f16)lv, lo = (f16)(lv - (float)hi);
+            lut[threadIdx.x] = (uint32_t)__builtin_bit_cast(uint16_t, hi) | ((uint32_t)__builtin_bit_cast(uint16_t, lo) << 16);
+        }
+        __syncthreads();
+        const uint32_t nblk = K >> 6, iters = (nblk + NW - 1) / NW;
+        const uint8_t* arow[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) arow[i] = P.w + (size_t)min(m0 + 4 * g + i, P.m - 1) * P.row_bytes + (K >> 1);      // absmax f16 per 64
+        for (uint32_t it = 0; it < iters; ++it) {
+            const uint32_t b0 = wave + NW * it, b = min(b0, nblk - 1);
+            uint32_t qw[2], am[4];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) qw[h] = *(const uint32_t*)(wrow + (size_t)b * 32 + h * 16 + 4 * g);      // 8 nibbles = this lane's 8 k of step h
+#pragma unroll
+            for (int i = 0; i < 4; ++i) am[i] = *(const uint16_t*)(arow[i] + (size_t)b * 2);
+            f16x8 bfr[2][NT];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) bfr[h][t] = loadB(t, b * 64 + h * 32);
+            f32x4v acc[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f16x8 ahi, alo;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const uint32_t pr = lut[(qw[h] >> (4 * e)) & 15u];
+                    ahi[e] = __builtin_bit_cast(f16, (uint16_t)(pr & 0xffffu));
+                    alo[e] = __builtin_bit_cast(f16, (uint16_t)(pr >> 16));
+                }
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    acc[t] = mfma16(ahi, bfr[h][t], acc[t]);
+                    acc[t] = mfma16(alo, bfr[h][t], acc[t]);
+                }
+            }
+            const float livef = b0 < nblk ? 1.0f : 0.0f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float a = (float)__builtin_bit_cast(f16, (uint16_t)am[i]) * livef;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) total[t][i] = __builtin_fmaf(a, acc[t][i], total[t][i]);
+            }
+        }
+        __syncthreads();        // the table shares the partial-sum array's allocation tail: done with it before the combine writes
     } else if (KIND == WRK_MAT_Q6_K) {
         const uint32_t iters = (nb + NW - 1) / NW;
         const uint8_t* drow[4];
@@ -433,7 +489,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& P, float (*sh_tot)[N
 // One launch, several matrices: blockIdx.x -> job (like the matvec launches), kind dispatched at run time.
 template <int NT, int NW>
 __global__ void __launch_bounds__(64 * NW) gemm_kernel(const GemmBatch B) {
-    __shared__ float sh_tot[NW - 1][NT][4][64];     // K-split partial sums of waves 1..NW-1
+    __shared__ float sh_tot[NW - 1 + 1][NT][4][64];     // K-split partial sums of waves 1..NW-1 (+ one slab: the NF4 level table lives in its head)
     int ji = 0;
 #pragma unroll
     for (int q = 1; q < GEMM_MAX_JOBS; ++q)
@@ -445,6 +501,7 @@ __global__ void __launch_bounds__(64 * NW) gemm_kernel(const GemmBatch B) {
         case WRK_MAT_Q6_K: gemm_body<WRK_MAT_Q6_K, NT, NW>(P, sh_tot); break;
         case WRK_MAT_Q8_0: gemm_body<WRK_MAT_Q8_0, NT, NW>(P, sh_tot); break;
         case WRK_MAT_INT8: gemm_body<WRK_MAT_INT8, NT, NW>(P, sh_tot); break;
+        case WRK_MAT_NF4: gemm_body<WRK_MAT_NF4, NT, NW>(P, sh_tot); break;
         default: gemm_body<WRK_MAT_F16, NT, NW>(P, sh_tot); break;
     }
 }
@@ -1060,6 +1117,7 @@ static bool gemm_ok(const MatJob& j, uint32_t n) {
     switch (j.kind) {
         case WRK_MAT_F16: case WRK_MAT_Q8_0: case WRK_MAT_Q6_K: case WRK_MAT_Q4_K: case WRK_MAT_Q5_K: return true;
         case WRK_MAT_INT8: return (j.k & 127u) == 0;      // rows aligned to the 128-element blocks
+        case WRK_MAT_NF4: return (j.k & 63u) == 0 && j.aux != nullptr;
         default: return false;
     }
 }
@@ -1074,6 +1132,7 @@ static void fill_job(GemmParams& P, const MatJob& j, uint32_t n, uint32_t wg_beg
     P.out_p = (char*)j.out.p + stack_base(j.out) * (P.out32 ? 4 : 2);
     P.res32 = j.has_res && j.res.dtype == WRK_F32; P.rs = j.has_res ? j.res.stride[0] : 0;
     P.res_p = j.has_res ? (const char*)j.res.p + stack_base(j.res) * (P.res32 ? 4 : 2) : nullptr;
+    P.levels = (const float*)j.aux;
 }
 
 int matmul_mfma_multi(hipStream_t s, const MatJob* jobs, int njobs, int) {
