@@ -1270,6 +1270,13 @@ static int launch_dmv(hipStream_t s, const MatvecParams& P, uint32_t total_wg, i
         if (j > 0) bounds[j - 1] = J.wg_begin;
     }
     if (xi > 8) return -1;
+    // Launches that stream tens of MB are bound by their steady state, not their start-up: there the first-generation kernels are
+    // ~3 % faster (RWKV-6 7B Q5_K_M, 40-57 MB per launch: 2.89 vs 2.99 ms per token; the 2.9B model's 12-15 MB launches are 16 %
+    // faster on the dmv kernels, round 2).  WRK_DMV_MAXMB moves the line.
+    static const size_t max_bytes = [] { const char* e = getenv("WRK_DMV_MAXMB"); return (size_t)(e ? atoi(e) : 24) << 20; }();
+    size_t launch_bytes = 0;
+    for (int j = 0; j < P.njobs; ++j) launch_bytes += (size_t)P.jobs[j].m * P.jobs[j].row_bytes;
+    if (launch_bytes > max_bytes && pro != 3 && pro != 4) return -1;        // (the split-head prologue exists in the dmv kernels only)
     dmv_fn fn = nullptr;
     const int ka = quant < 0 ? WRK_MAT_F16 : quant;
     const bool mixf = has_f16 && quant >= 0;
