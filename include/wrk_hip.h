@@ -16,13 +16,18 @@
  *     addressed through `wrk_view` == `View { shape, stride, offset }` (src/tensor/mod.rs:27-44):
  *     element(b, t, c) = ((b + offset[2]) * stride[1] + (t + offset[1])) * stride[0] + c + offset[0]
  *     (`stride` holds the parent tensor's dims, as in the WGSL `compute_index` helpers).
- *   - `wrk_op_*` functions ENQUEUE work on the context's stream (they are the HIP analogue of
- *     building a TensorOp and encoding it); between `wrk_capture_begin/end` they are recorded
- *     into a `wrk_program` (a hipGraph) instead, which is the analogue of the CommandBuffer the
+ *   - `wrk_op_*` functions ENQUEUE work on the context's submission stream (they are the HIP analogue of
+ *     building a TensorOp and encoding it); between `wrk_capture_begin/end` ON THE SAME THREAD they are
+ *     recorded into a `wrk_program` (a hipGraph) instead, which is the analogue of the CommandBuffer the
  *     reference keeps in an `RnnJob` (src/runtime/v7.rs:423-432) and replays with `queue.submit`.
- *   - thread-safety: a context may be used from several threads, calls on one context are
- *     serialised by an internal mutex; `wrk_buf_read` uses its own stream so the reference's
- *     read-back thread (src/context.rs:148-162) can block without stalling submissions.
+ *   - threading = the reference's: jobs are ENCODED concurrently on tokio `spawn_blocking` workers
+ *     while the runtime task SUBMITS cached ones (src/runtime/mod.rs:139-167) and a dedicated thread blocks in
+ *     read-backs (src/context.rs:148-162).  A capture belongs to the thread that began it and records on a
+ *     private stream: the submission stream and the read-back stream are never in capture mode, any number of
+ *     threads may have a capture open, and launches / uploads / allocations / reads from other threads proceed
+ *     meanwhile.  Individual calls on one context are serialised by an internal mutex (a capture is not).
+ *     Nothing recorded executes before its program is launched; `wrk_buf_write` is never recorded (it is
+ *     `queue.write_buffer`, not an encoder command); `wrk_buf_copy` and the state snapshot copies are.
  */
 #ifndef WRK_HIP_H
 #define WRK_HIP_H

@@ -60,4 +60,11 @@ def test_f32_frames_meet_1e3(ctx, name, weights, kw):
         d = np.abs(rt.state_back(b) - oracle.state.back(b))
         assert d.max() <= 1e-4 * max(1.0, float(np.abs(oracle.state.back(b)).max())), d.max()
     print(name, "max |logit - oracle| with f32 frames:", worst)
+    import json
+    import os
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "f32_frames.json")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    data = json.load(open(out)) if os.path.exists(out) else {}
+    data[f"{name}/{weights}/{sorted(kw.items())}"] = worst
+    json.dump(data, open(out, "w"), indent=1, sort_keys=True)
     rt.close()
