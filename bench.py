@@ -308,9 +308,14 @@ def main():
     ap.add_argument("--model", default="1.5B", choices=sorted(CONFIGS) + sorted(CONFIGS_V6))
     ap.add_argument("--batch", type=int, default=1, help="independent streams per GPU")
     ap.add_argument("--mode", type=int, default=1, help="1 = fused decode kernels, 0 = one kernel per reference op")
+    ap.add_argument("--groups", type=int, default=1, help="deal the --batch streams of a GPU over this many concurrent decode pipelines (RWKV-7; 1 = one batched step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--quant", default="", help="ModelBuilder::quant map, e.g. int8:0-29,nf4:30-60 (layers inclusive)")
     ap.add_argument("--mixed", action="store_true", help="llama.cpp Q4_K_M tensor mix: Q6_K for attn value / ffn value in about half of the layers")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="backend of the timing barrier / max-reduce (the only communication); nccl == RCCL.  gloo allows a rehearsal of N ranks on a box with fewer GPUs")
+    ap.add_argument("--device-map", default="", help="rehearsal only: comma list, local rank -> HIP device (e.g. 0,0 runs two ranks on one GPU; needs --dist-backend gloo)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise the process group even for one rank (exercises the RCCL path on a one-GPU box)")
     ap.add_argument("--stub-device", action="store_true",
                     help="TEST ONLY (tests/test_bench_launcher.py): exercise the launcher, the rank rendezvous (gloo) and the aggregation "
                          "without a GPU; the decode step is replaced by a sleep and the JSON line is marked \"data\": \"stub\"")
@@ -325,18 +330,24 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
     dist = None
-    if world > 1:
+    device = local_rank
+    if args.device_map:
+        device = int(args.device_map.split(",")[local_rank])
+    use_gloo = args.stub_device or args.dist_backend == "gloo"
+    if world > 1 or args.force_dist:
         import torch
         import torch.distributed as dist
-        if args.stub_device:
+        if args.force_dist and "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+        if use_gloo:
             dist.init_process_group("gloo")
         else:
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            torch.cuda.set_device(device)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
 
     sys.path.insert(0, os.path.join(ROOT, "web-rwkv-gguf_amd", "wrk"))
     import replicas         # no GPU dependency (the stub ranks import nothing else of the package)
-    group = replicas.ReplicaGroup(dist, device="cuda" if (dist is not None and not args.stub_device) else None)
+    group = replicas.ReplicaGroup(dist, device="cuda" if (dist is not None and not use_gloo) else None)
     B = args.batch
     streams = group.my_streams(world * B)           # global ids of the independent sequences this rank owns
     assert len(streams) == B
@@ -362,7 +373,7 @@ def main():
     t0 = time.time()
     # every rank builds the SAME weights (a replica): seed 42
     gg = make_model_gguf(args.model, seed=42, mixed=args.mixed) if args.model not in CONFIGS_V6 else make_model_gguf(args.model, seed=42)
-    ctx = wrk.Context(local_rank)
+    ctx = wrk.Context(device)
     reader = wrk.GgufReader(gg)
     quant = {}
     for part in filter(None, args.quant.split(",")):
@@ -378,15 +389,16 @@ def main():
     def barrier():
         ctx.sync()
         if dist is not None:
-            import torch
             group.barrier()
-            torch.cuda.synchronize()
+            if not use_gloo:
+                import torch
+                torch.cuda.synchronize()
 
     if args.warmup > 0:
-        runtime.generate_greedy(first, args.warmup, mode=args.mode)
+        runtime.generate_greedy(first, args.warmup, mode=args.mode, groups=args.groups)
     barrier()
     w0 = time.perf_counter()
-    toks, dev_ms = runtime.generate_greedy(first, args.steps, mode=args.mode)     # HIP events on the ctx stream
+    toks, dev_ms = runtime.generate_greedy(first, args.steps, mode=args.mode, groups=args.groups)     # HIP events on the ctx stream
     ctx.sync()
     wall_ms = (time.perf_counter() - w0) * 1e3
     barrier()
@@ -408,7 +420,8 @@ def main():
                                     if args.model in CONFIGS_V6 else
                                     f"RWKV-7 World {args.model} Q4_K_M ({'llama.cpp mix: Q4_K + Q6_K attn/ffn value' if args.mixed else 'Q4_K matrices'}, Q6_K head, F16 LoRA) batch={B} greedy decode, ") +
                                    f"{'fused kernels' if args.mode == 1 else 'one kernel per reference op'} under hipGraph",
-                       "streams_per_gpu": B, "streams": world * B, "parallelism": f"replicas x{world}" if world > 1 else "single"},
+                       "streams_per_gpu": B, "pipelines_per_gpu": args.groups, "streams": world * B, "parallelism": f"replicas x{world}" if world > 1 else "single",
+                       **({"rehearsal": f"device map {args.device_map}, {args.dist_backend} barrier: ranks SHARE GPUs, not a scaling number"} if args.device_map else {})},
             # per GPU: every replica streams its own copy of the weights
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,

@@ -300,7 +300,11 @@ int32_t wrk_v7_frame_read(wrk_ctx* ctx, wrk_v7_model* model, const char* name, u
  * with softmax+argmax moved on device): every sequence b feeds `first_tokens[b]`, then its own
  * argmax, for `steps` steps.  out_tokens: host u32 [steps, num_batch] or NULL.  One hipGraph per
  * step shape is built on first use and replayed.  elapsed_ms_or_null receives the HIP-event time
- * of the `steps` replays on the context's stream. */
+ * of the `steps` replays on the context's stream.
+ * mode: bits 0-7 as wrk_v7_infer (0 op-by-op, 1 fused); bits 8-15 = G > 1: the num_batch INDEPENDENT sequences (separate state
+ * slices, v7.rs:519-521) are dealt in contiguous blocks over G concurrent pipelines -- each with its own Runtime<F> frame, cached
+ * step program and HIP stream, all sharing the one set of weights -- so that several latency-bound decode pipelines overlap on the
+ * GPU (the in-GPU analogue of sharding streams over GPUs; results equal running each block on its own). */
 int32_t wrk_v7_generate_greedy(wrk_ctx* ctx, wrk_v7_model* model, wrk_v7_state* state,
                                const uint32_t* first_tokens, uint32_t num_batch, uint32_t steps,
                                uint32_t* out_tokens, float* last_logits_or_null, float* elapsed_ms_or_null, uint32_t mode);

@@ -247,3 +247,33 @@ def test_merged_prefill_launches_are_bit_identical_to_the_op_list(ctx, name, kw)
     for x, y in zip(l0 + n0, l1 + n1):
         assert np.array_equal(x, y), float(np.abs(x - y).max())
     assert np.array_equal(a0, a1) and np.array_equal(b0, b1)
+
+
+@pytest.mark.parametrize("B,groups", [(4, 2), (6, 3), (5, 5), (8, 2)])
+def test_concurrent_pipelines_equal_separate_runs(ctx, B, groups):
+    """generate_greedy with G concurrent pipelines (mode bits 8-15): the sequences are independent (separate state slices,
+    v7.rs:519-521), so every block must produce exactly what it produces when decoded alone through the ordinary call --
+    same kernels, same shapes, bit-identical tokens, logits and state -- and the oracle's greedy tokens."""
+    data = synth.make_v7_gguf(synth.CONFIGS["small"], 42)
+    V = synth.CONFIGS["small"].num_vocab
+    first = [(13 + 97 * b) % (V - 1) for b in range(B)]
+    rt = wrk.Runtime(ctx, wrk.GgufReader(data), num_batch=B)
+    toks, ms, logits = rt.generate_greedy(first, 9, mode=1, want_logits=True, groups=groups)
+    states = [rt.state_back(b) for b in range(B)]
+    rt.close()
+    assert toks.shape == (9, B) and ms > 0
+    for g in range(groups):
+        b0, b1 = B * g // groups, B * (g + 1) // groups
+        alone = wrk.Runtime(ctx, wrk.GgufReader(data), num_batch=b1 - b0)
+        t, _, l = alone.generate_greedy(first[b0:b1], 9, mode=1, want_logits=True)
+        assert np.array_equal(toks[:, b0:b1], t)
+        assert np.array_equal(logits[b0:b1], l)
+        for b in range(b0, b1):
+            assert np.array_equal(states[b], alone.state_back(b - b0))
+        alone.close()
+    oracle = O.V7Runtime(O.build_v7(ogguf.GgufReader(data), weights_f16=False), B, act_f16=True)
+    cur = list(first)
+    for step in range(9):
+        ol = oracle.infer_chunk([[t] for t in cur], list(range(B)))
+        cur = [int(ol[b].argmax()) for b in range(B)]
+        assert toks[step].tolist() == cur, step

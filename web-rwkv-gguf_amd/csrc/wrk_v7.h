@@ -61,6 +61,13 @@ struct wrk_v7_model {
     // is generic over F).  F32 frames always take the op-by-op path with the f32-input matvec.
     uint32_t act_dtype = WRK_F16;
 
+    // Concurrent pipelines (generate_greedy with groups > 1): lane g is a clone of this model -- same weight handles, its own frame,
+    // history and cached programs -- whose decode graphs are replayed on a stream of its own, so that several latency-bound
+    // pipelines overlap on the GPU (independent sequences: separate state slices, no synchronisation between lanes)
+    std::vector<wrk_v7_model*> lanes;
+    std::vector<hipStream_t> lane_streams;
+    std::vector<hipEvent_t> lane_events;
+
     int32_t ensure_scratch(uint32_t T, uint32_t NH);
     int32_t ensure_history(size_t n);
     void drop_graphs();

@@ -323,7 +323,13 @@ int32_t wrk_v7_model_destroy(wrk_v7_model* m) {
         for (auto& kv : m->graphs) wrk_program_destroy(kv.second);
         if (m->scratch) hipFree(m->scratch);
         m->free_fused();
+        for (hipStream_t s : m->lane_streams) { hipStreamSynchronize(s); hipStreamDestroy(s); }
+        for (hipEvent_t e : m->lane_events) hipEventDestroy(e);
+        m->lane_streams.clear(); m->lane_events.clear();
     }
+    for (wrk_v7_model* lane : m->lanes) wrk_v7_model_destroy(lane);
+    m->lanes.clear();
+    if (m->history) { LOCK(ctx); hipFree(m->history); m->history = nullptr; }
     auto fb = [](const wrk_buf* b) { if (b) wrk_buf_release(const_cast<wrk_buf*>(b)); };
     auto fm = [](const wrk_matrix* x) { if (x) wrk_matrix_release(const_cast<wrk_matrix*>(x)); };
     fb(m->ln0_w); fb(m->ln0_b); fb(m->ln_out_w); fb(m->ln_out_b); fb(m->emb); fm(m->head);
@@ -608,69 +614,125 @@ int32_t wrk_v7_frame_read(wrk_ctx* ctx, wrk_v7_model* m, const char* name, uint3
     return wrk_fail(ctx, WRK_E_ARG, "no frame buffer named %s", name);
 }
 
-int32_t wrk_v7_generate_greedy(wrk_ctx* ctx, wrk_v7_model* m, wrk_v7_state* st, const uint32_t* first_tokens, uint32_t B,
-                               uint32_t steps, uint32_t* out_tokens, float* last_logits, float* elapsed_ms, uint32_t mode) {
-    if (!ctx || !m || !st || !first_tokens) return WRK_E_ARG;
-    LOCK(ctx);
-    WRK_HIP(ctx, hipSetDevice(ctx->device));
-    WRK_ARG(ctx, m->emb, "generate_greedy needs the device embedding table");
-    WRK_ARG(ctx, B >= 1 && B <= st->num_batch, "num_batch %u exceeds the state's %u", B, st->num_batch);
-    WRK_ARG(ctx, st->num_emb == m->d.num_emb && st->num_layer == m->d.num_layer, "state does not belong to this model");
+// generate_greedy, part 1: frame, token / cursor upload and the (cached) decode-step program of sequences [b0, b0 + B) on model frame `m`
+static int32_t greedy_prepare(wrk_ctx* ctx, wrk_v7_model* m, wrk_v7_state* st, const uint32_t* first_tokens, uint32_t b0, uint32_t B,
+                              uint32_t steps, uint32_t mode, bool eager, wrk_program** prog_out) {
     const uint32_t D = m->d.num_emb, V = m->d.num_vocab;
-    for (uint32_t b = 0; b < B; ++b) WRK_ARG(ctx, first_tokens[b] < V, "first token %u out of vocab", first_tokens[b]);
-    if (elapsed_ms) *elapsed_ms = 0.0f;
-    if (steps == 0) return WRK_OK;
     int32_t rc = m->ensure_scratch(B, B);
     if (rc != WRK_OK) return rc;
     rc = m->ensure_history((size_t)steps * B);
     if (rc != WRK_OK) return rc;
     std::vector<uint32_t> cur(B), hdr(B);
-    for (uint32_t b = 0; b < B; ++b) { cur[b] = b | (b << 8) | (1u << 24); hdr[b] = b; }
+    for (uint32_t b = 0; b < B; ++b) { cur[b] = (b0 + b) | (b << 8) | (1u << 24); hdr[b] = b; }
     rc = wrk_buf_write_raw(ctx, m->s.cursors, cur.data(), (size_t)B * 4);
     if (rc == WRK_OK) rc = wrk_buf_write_raw(ctx, m->s.headers, hdr.data(), (size_t)B * 4);
     if (rc == WRK_OK) rc = wrk_buf_write_raw(ctx, m->s.tokens, first_tokens, (size_t)B * 4);
     if (rc != WRK_OK) return rc;
     WRK_HIP(ctx, hipMemsetAsync(m->s.counter, 0, 4, ctx->stream));
     WRK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *prog_out = nullptr;
+    if (eager) return WRK_OK;
+    // one graph per (state, first sequence, B, mode): the analogue of the reference's cached RnnJob for a repeated RnnInfo
+    const wrk_v7_model::GraphKey key{st->uid, B | (b0 << 16), mode | (m->act_dtype == WRK_F32 ? 4u : 0u)};
+    auto it = m->graphs.find(key);
+    if (it != m->graphs.end()) { *prog_out = it->second; return WRK_OK; }
+    rc = wrk_capture_begin(ctx);
+    if (rc != WRK_OK) return rc;
+    if (mode == 1 && m->act_dtype == WRK_F16) rc = m->enqueue_fused_decode(st, B, B, true, true, true, true, b0);
+    else {
+        wrk::gather_rows_f16(ctx->op_stream(), m->emb->ptr, m->s.tokens, m->s.input, D, B);
+        rc = m->enqueue_ops(st, B, B, true);
+        if (rc == WRK_OK) {
+            wrk::argmax_rows(ctx->op_stream(), m->s.head_o, V, V, B, m->s.argmax);
+            wrk::advance_tokens(ctx->op_stream(), m->s.argmax, m->s.tokens, m->history, m->s.counter, B);
+        }
+    }
+    wrk_program* p = nullptr;
+    const int32_t rc2 = wrk_capture_end(ctx, &p);
+    if (rc != WRK_OK) { if (p) wrk_program_destroy(p); return rc; }
+    if (rc2 != WRK_OK) return rc2;
+    m->graphs[key] = p;
+    *prog_out = p;
+    return WRK_OK;
+}
 
-    // one graph per (state, B, mode): the analogue of the reference's cached RnnJob for a repeated RnnInfo.
-    // WRK_NO_GRAPH=1 enqueues every step eagerly instead (used under rocprofv3 kernel tracing).
+int32_t wrk_v7_generate_greedy(wrk_ctx* ctx, wrk_v7_model* m, wrk_v7_state* st, const uint32_t* first_tokens, uint32_t B,
+                               uint32_t steps, uint32_t* out_tokens, float* last_logits, float* elapsed_ms, uint32_t mode_arg) {
+    if (!ctx || !m || !st || !first_tokens) return WRK_E_ARG;
+    LOCK(ctx);
+    WRK_HIP(ctx, hipSetDevice(ctx->device));
+    WRK_ARG(ctx, m->emb, "generate_greedy needs the device embedding table");
+    WRK_ARG(ctx, B >= 1 && B <= st->num_batch, "num_batch %u exceeds the state's %u", B, st->num_batch);
+    WRK_ARG(ctx, st->num_emb == m->d.num_emb && st->num_layer == m->d.num_layer, "state does not belong to this model");
+    const uint32_t V = m->d.num_vocab;
+    for (uint32_t b = 0; b < B; ++b) WRK_ARG(ctx, first_tokens[b] < V, "first token %u out of vocab", first_tokens[b]);
+    if (elapsed_ms) *elapsed_ms = 0.0f;
+    if (steps == 0) return WRK_OK;
+    // mode: bits 0-7 = 0 op-by-op / 1 fused; bits 8-15 = number of concurrent pipelines the sequences are dealt over (0, 1: one)
+    const uint32_t mode = mode_arg & 0xffu;
+    uint32_t groups = (mode_arg >> 8) & 0xffu;
+    if (groups < 1) groups = 1;
+    if (groups > B) groups = B;
     const char* ng = getenv("WRK_NO_GRAPH");
     const bool eager = ng && ng[0] == '1';
+    WRK_ARG(ctx, groups == 1 || !eager, "concurrent pipelines replay captured programs: not with WRK_NO_GRAPH=1");
     wrk::timing_slot(ctx, nullptr);     // WRK_TIMING=1: allocate the stamp buffer outside the capture
-    auto enqueue_step = [&]() -> int32_t {
-        if (mode == 1 && m->act_dtype == WRK_F16) return m->enqueue_fused_decode(st, B, B, true, true, true, true, 0);
-        wrk::gather_rows_f16(ctx->op_stream(), m->emb->ptr, m->s.tokens, m->s.input, D, B);
-        int32_t r = m->enqueue_ops(st, B, B, true);
-        if (r != WRK_OK) return r;
-        wrk::argmax_rows(ctx->op_stream(), m->s.head_o, V, V, B, m->s.argmax);
-        wrk::advance_tokens(ctx->op_stream(), m->s.argmax, m->s.tokens, m->history, m->s.counter, B);
-        return WRK_OK;
-    };
-    const wrk_v7_model::GraphKey key{st->uid, B, mode | (m->act_dtype == WRK_F32 ? 4u : 0u)};
-    wrk_program* prog = nullptr;
-    if (!eager) {
-        auto it = m->graphs.find(key);
-        if (it != m->graphs.end()) prog = it->second;
-        else {
-            rc = wrk_capture_begin(ctx);
-            if (rc != WRK_OK) return rc;
-            rc = enqueue_step();
-            wrk_program* p = nullptr;
-            int32_t rc2 = wrk_capture_end(ctx, &p);
-            if (rc != WRK_OK) { if (p) wrk_program_destroy(p); return rc; }
-            if (rc2 != WRK_OK) return rc2;
-            prog = p;
-            m->graphs[key] = prog;
-        }
+
+    // lanes: lane 0 is this model's own frame; lanes 1.. are clones sharing the weight handles
+    while (m->lanes.size() + 1 < groups) {
+        wrk_v7_model* lane = nullptr;
+        const int32_t rc = wrk_v7_model_create(ctx, &m->d, &lane);
+        if (rc != WRK_OK) return rc;
+        lane->act_dtype = m->act_dtype;
+        m->lanes.push_back(lane);
+    }
+    while (m->lane_streams.size() < groups) {
+        hipStream_t s = nullptr;
+        hipEvent_t e = nullptr;
+        WRK_HIP(ctx, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        WRK_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        m->lane_streams.push_back(s);
+        m->lane_events.push_back(e);
+    }
+    struct Lane { wrk_v7_model* mdl; uint32_t b0, nb; wrk_program* prog; };
+    std::vector<Lane> L(groups);
+    for (uint32_t g = 0; g < groups; ++g) {
+        L[g].mdl = g == 0 ? m : m->lanes[g - 1];
+        L[g].b0 = (uint32_t)((uint64_t)B * g / groups);
+        L[g].nb = (uint32_t)((uint64_t)B * (g + 1) / groups) - L[g].b0;
+        const int32_t rc = greedy_prepare(ctx, L[g].mdl, st, first_tokens + L[g].b0, L[g].b0, L[g].nb, steps, mode, eager, &L[g].prog);
+        if (rc != WRK_OK) return rc;
     }
     hipEvent_t e0, e1;
     WRK_HIP(ctx, hipEventCreate(&e0));
     WRK_HIP(ctx, hipEventCreate(&e1));
     WRK_HIP(ctx, hipEventRecord(e0, ctx->stream));
-    for (uint32_t i = 0; i < steps; ++i) {
-        if (eager) { rc = enqueue_step(); if (rc != WRK_OK) return rc; }
-        else WRK_HIP(ctx, hipGraphLaunch(prog->exec, ctx->stream));
+    if (groups == 1) {
+        for (uint32_t i = 0; i < steps; ++i) {
+            if (eager) {
+                int32_t rc;
+                if (mode == 1 && m->act_dtype == WRK_F16) rc = m->enqueue_fused_decode(st, B, B, true, true, true, true, 0);
+                else {
+                    wrk::gather_rows_f16(ctx->op_stream(), m->emb->ptr, m->s.tokens, m->s.input, m->d.num_emb, B);
+                    rc = m->enqueue_ops(st, B, B, true);
+                    if (rc == WRK_OK) {
+                        wrk::argmax_rows(ctx->op_stream(), m->s.head_o, V, V, B, m->s.argmax);
+                        wrk::advance_tokens(ctx->op_stream(), m->s.argmax, m->s.tokens, m->history, m->s.counter, B);
+                    }
+                }
+                if (rc != WRK_OK) return rc;
+            } else WRK_HIP(ctx, hipGraphLaunch(L[0].prog->exec, ctx->stream));
+        }
+    } else {
+        // every lane replays its own step program on its own stream; the lanes start together behind e0 and the submission
+        // stream joins them all before e1
+        for (uint32_t g = 0; g < groups; ++g) WRK_HIP(ctx, hipStreamWaitEvent(m->lane_streams[g], e0, 0));
+        for (uint32_t i = 0; i < steps; ++i)
+            for (uint32_t g = 0; g < groups; ++g) WRK_HIP(ctx, hipGraphLaunch(L[g].prog->exec, m->lane_streams[g]));
+        for (uint32_t g = 0; g < groups; ++g) {
+            WRK_HIP(ctx, hipEventRecord(m->lane_events[g], m->lane_streams[g]));
+            WRK_HIP(ctx, hipStreamWaitEvent(ctx->stream, m->lane_events[g], 0));
+        }
     }
     WRK_HIP(ctx, hipEventRecord(e1, ctx->stream));
     WRK_HIP(ctx, hipEventSynchronize(e1));
@@ -679,8 +741,15 @@ int32_t wrk_v7_generate_greedy(wrk_ctx* ctx, wrk_v7_model* m, wrk_v7_state* st, 
     hipEventDestroy(e0);
     hipEventDestroy(e1);
     if (elapsed_ms) *elapsed_ms = ms;
-    if (out_tokens) WRK_HIP(ctx, hipMemcpyAsync(out_tokens, m->history, (size_t)steps * B * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (last_logits) WRK_HIP(ctx, hipMemcpyAsync(last_logits, m->s.head_o, (size_t)B * V * 4, hipMemcpyDeviceToHost, ctx->stream));
+    for (uint32_t g = 0; g < groups; ++g) {
+        const Lane& ln = L[g];
+        if (out_tokens) {
+            if (groups == 1) WRK_HIP(ctx, hipMemcpyAsync(out_tokens, ln.mdl->history, (size_t)steps * B * 4, hipMemcpyDeviceToHost, ctx->stream));
+            else WRK_HIP(ctx, hipMemcpy2DAsync(out_tokens + ln.b0, (size_t)B * 4, ln.mdl->history, (size_t)ln.nb * 4, (size_t)ln.nb * 4, steps,
+                                               hipMemcpyDeviceToHost, ctx->stream));
+        }
+        if (last_logits) WRK_HIP(ctx, hipMemcpyAsync(last_logits + (size_t)ln.b0 * V, ln.mdl->s.head_o, (size_t)ln.nb * V * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
     WRK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     wrk::timing_report(ctx);
     return WRK_OK;

@@ -705,8 +705,11 @@ class Runtime:
         self.ctx.check(hip.wrk_v7_frame_read(self.ctx.h, self.model, name.encode(), num_token, out.ctypes.data_as(_P), out.nbytes, C.byref(n)))
         return out.reshape(num_token, -1)
 
-    def generate_greedy(self, first_tokens, steps: int, mode: int = 1, want_logits: bool = False):
-        """Device-resident greedy loop; returns (tokens [steps, B], elapsed_ms[, last logits [B, V]])."""
+    def generate_greedy(self, first_tokens, steps: int, mode: int = 1, want_logits: bool = False, groups: int = 1):
+        """Device-resident greedy loop; returns (tokens [steps, B], elapsed_ms[, last logits [B, V]]).
+        groups > 1 (RWKV-7): the B independent sequences are dealt over that many concurrent pipelines (each a contiguous block of
+        sequences with its own frame, decode program and HIP stream) instead of one batched step."""
+        mode = (mode & 0xff) | ((groups & 0xff) << 8 if groups > 1 and not self.model6 else 0)
         ft = _u32(first_tokens)
         B = ft.size
         out = np.zeros((steps, B), np.uint32)
