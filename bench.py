@@ -117,6 +117,10 @@ CONFIGS_V6 = {      # SURVEY section 8 cfg 4 / 5: L, D, F, V, time_mix rank, tim
     "v6-tiny": (2, 256, 896, 512, 32, 64),
     "v6-7B": (32, 4096, 14336, 65536, 64, 128),
     "v6-14B": (61, 4096, 14336, 65536, 64, 128),        # cfg 5: Q8_0 file + per-layer Int8 / NF4 map (--quant)
+    # three layers of the cfg 4 / cfg 5 layer shape with a small vocabulary: the real matrix widths (K = 4096, 14336) at a size the
+    # NumPy oracle can follow (tests/test_gpu_v6_fullshape.py)
+    "v6-7B-3L": (3, 4096, 14336, 8192, 64, 128),
+    "v6-14B-3L": (3, 4096, 14336, 8192, 64, 128),
 }
 
 
@@ -132,7 +136,7 @@ def make_model_gguf_v6(name, seed=42):
     """RWKV-6 "World" architecture, Q5_K_M-style: Q5_K matrices, Q6_K head, F16 embedding, F32 LoRA / vectors
     (names: gguf.rs:1198-1251); the 14B config is a Q8_0 file (cfg 5)."""
     L, D, F, V, R, W = CONFIGS_V6[name]
-    q8 = name == "v6-14B"
+    q8 = name.startswith("v6-14B")
     mat_id = 8 if q8 else 13
     mat_blocks = _q8_0_blocks if q8 else _q5k_blocks
     rng = np.random.default_rng(seed)
@@ -295,7 +299,7 @@ def launch_replicas(n, argv):
 def metric_name(model, batch, world):
     """BASELINE.json's metric string for the headline workload; the same wording with the model / quantisation / stream
     count actually run for every other configuration."""
-    fam, size, quant = ("RWKV-6", model[3:], "Q8_0" if model == "v6-14B" else "Q5_K_M") if model in CONFIGS_V6 else ("RWKV-7", model, "Q4_K_M")
+    fam, size, quant = ("RWKV-6", model[3:], "Q8_0" if model.startswith("v6-14B") else "Q5_K_M") if model in CONFIGS_V6 else ("RWKV-7", model, "Q4_K_M")
     streams = "" if batch == 1 else f" batch={batch}/GPU"
     return f"tokens/sec {fam} {size} {quant} decode{streams} @{world} GPU; achieved HBM GB/s vs roofline"
 
@@ -415,7 +419,7 @@ def main():
             "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
-            "config": {"workload": (f"RWKV-6 World {args.model[3:]} {'Q8_0' if args.model == 'v6-14B' else 'Q5_K_M (Q5_K matrices)'}, Q6_K head, F16 LoRA"
+            "config": {"workload": (f"RWKV-6 World {args.model[3:]} {'Q8_0' if args.model.startswith('v6-14B') else 'Q5_K_M (Q5_K matrices)'}, Q6_K head, F16 LoRA"
                                     f"{', quant map ' + args.quant if args.quant else ''}, batch={B} greedy decode, "
                                     if args.model in CONFIGS_V6 else
                                     f"RWKV-7 World {args.model} Q4_K_M ({'llama.cpp mix: Q4_K + Q6_K attn/ffn value' if args.mixed else 'Q4_K matrices'}, Q6_K head, F16 LoRA) batch={B} greedy decode, ") +
