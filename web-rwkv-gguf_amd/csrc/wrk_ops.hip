@@ -419,21 +419,25 @@ __global__ void __launch_bounds__(256) time_mix_v7_fast_kernel(const uint32_t* _
     const f16* vp = (const f16*)n.p + dt_index4(n, i, head, cur.token, 1);
     const f16* wp = (const f16*)w.p + dt_index(w, tid & 63u, head, cur.token);
     f16* xp = (f16*)x.p + dt_index(x, i, head, cur.token);
-    auto load_tok = [&](Tok& T) {       // loads the token the pointers stand on, then advances them
+    // Every load is unconditional (round 2): the predicated form (`if (more) load`, `if (tid < 64) wraw = *wp`) made the compiler wait
+    // vmcnt(0) right behind the prefetch, so each token paid a full memory round trip (2.8 us per token in the 32 x 128 prefill).
+    // The pointers stop advancing at the last token instead (`adv` = 0): its prefetch re-reads that token and is discarded.
+    auto load_tok = [&](Tok& T, bool adv) {       // advances the pointers (unless at the end), then loads the token they stand on
+        const size_t rs = adv ? rstep : 0, ns = adv ? nstep : 0, ws = adv ? wstep : 0;
+        rp += rs; kp += ns; ap += ns; qp += ns; vp += ns; wp += ws;
         T.r[0] = *(const f16x8*)rp; T.r[1] = *(const f16x8*)(rp + 8);
         T.k[0] = *(const f16x8*)kp; T.k[1] = *(const f16x8*)(kp + 8);
         T.a[0] = *(const f16x8*)ap; T.a[1] = *(const f16x8*)(ap + 8);
         T.kk[0] = *(const f16x8*)qp; T.kk[1] = *(const f16x8*)(qp + 8);
         T.v = *vp;
-        if (tid < S) T.wraw = *wp;
-        rp += rstep; kp += nstep; ap += nstep; qp += nstep; vp += nstep; wp += wstep;
+        T.wraw = *wp;
     };
     Tok curT, nxtT;
-    load_tok(curT);
+    load_tok(curT, false);
     if (tid < S) sh_w[cur.token & 1u][tid] = __expf(-0.606531f * act_sigmoid((float)curT.wraw));
     for (uint32_t t = cur.token; t < tend; ++t) {
         const bool more = t + 1 < tend;
-        if (more) load_tok(nxtT);
+        load_tok(nxtT, more);
         __syncthreads();                                        // w~ of token t is in sh_w[t & 1]
         const float* wt = sh_w[t & 1u] + part * 16;
         float wv[16];
@@ -460,10 +464,9 @@ __global__ void __launch_bounds__(256) time_mix_v7_fast_kernel(const uint32_t* _
         y = (y + __shfl_xor(y, 2, WAVE));
         if (part == 0) *xp = (f16)y;
         xp += xstep;
-        if (more) {
-            if (tid < S) sh_w[(t + 1) & 1u][tid] = __expf(-0.606531f * act_sigmoid((float)nxtT.wraw));
-            curT = nxtT;
-        }
+        // w~ of the next token (harmless recomputation of the last token's at the end)
+        if (tid < S) sh_w[(t + 1) & 1u][tid] = __expf(-0.606531f * act_sigmoid((float)nxtT.wraw));
+        curT = nxtT;
     }
 #pragma unroll
     for (int jj = 0; jj < 16; ++jj) dt_store(st, dt_index(st, ch, 1 + part * 16 + jj, cur.batch), Sreg[jj]);
