@@ -284,6 +284,20 @@ __global__ void __launch_bounds__(256) dmv_kernel(uint32_t b1, uint32_t b2, uint
     else dmv_body<KB, (KB != WRK_MAT_F16) && R16, (KB == WRK_MAT_F16 ? 4 * XI : XI), 1, PRO>(J, smem);
 }
 
+// Three kinds in one launch: a K4 kind, Q6_K and F16 -- the r, k, v + LoRA stage of a real llama.cpp Q4_K_M / Q5_K_M file, whose attn
+// value is Q6_K in about half of the layers (KS == 1; the job's own kind field selects the body)
+template <int KA, bool R16, int XI, int PRO>
+__global__ void __launch_bounds__(256) dmv3_kernel(uint32_t b1, uint32_t b2, uint32_t b3, uint32_t b4, uint32_t b5, uint32_t b6, uint32_t b7,
+                                                   uint32_t, const DParams P) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[576 + (PRO > 0 ? ((PRO - 1) % 2 + 1) * 4096 : 16)];
+    const uint32_t b = blockIdx.x;
+    const uint32_t ji = (b >= b1) + (b >= b2) + (b >= b3) + (b >= b4) + (b >= b5) + (b >= b6) + (b >= b7);
+    const DJob J = P.jobs[ji];
+    if (J.kind == (uint32_t)KA) dmv_body<KA, R16, XI, 1, PRO>(J, smem);
+    else if (J.kind == WRK_MAT_Q6_K) dmv_body<WRK_MAT_Q6_K, R16, XI, 1, PRO>(J, smem);
+    else dmv_body<WRK_MAT_F16, false, 4 * XI, 1, PRO>(J, smem);
+}
+
 typedef void (*dmv_fn)(uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const DParams);
 
 template <int KA, int KB, int XI, int KS>
@@ -313,7 +327,7 @@ static dmv_fn pick_dmv_kind(int ka, bool has_f16, bool r16, int pro) {
 }
 
 // Host side of the dmv kernels: 0 = launched (or would be, dry), -1 = not eligible (the caller falls back to the first-generation kernels)
-int launch_dmv(hipStream_t s, const MatvecParams& P, uint32_t total_wg, int quant, bool has_f16, bool r16, bool dry) {
+int launch_dmv(hipStream_t s, const MatvecParams& P, uint32_t total_wg, int quant, bool has_f16, bool r16, bool dry, int quant2) {
     static const bool enabled = [] { const char* e = getenv("WRK_DMV"); return !(e && e[0] == '0'); }();
     if (!enabled) return -1;
     DParams D;
@@ -372,7 +386,14 @@ int launch_dmv(hipStream_t s, const MatvecParams& P, uint32_t total_wg, int quan
     dmv_fn fn = nullptr;
     const int ka = quant < 0 ? WRK_MAT_F16 : quant;
     const bool mixf = has_f16 && quant >= 0;
-    if (xi == 1) fn = pick_dmv_kind<1, 1>(ka, mixf, r16, pro);
+    if (quant2 >= 0) {      // (Q4_K | Q5_K) + Q6_K (+ F16): short rows, LN prologue or none
+        const int k4 = quant == WRK_MAT_Q6_K ? quant2 : quant;
+        if ((quant != WRK_MAT_Q6_K && quant2 != WRK_MAT_Q6_K) || (k4 != WRK_MAT_Q4_K && k4 != WRK_MAT_Q5_K) || xi != 1 || pro > 1) return -1;
+#define DMV3(A) (pro == 1 ? (r16 ? (dmv_fn)dmv3_kernel<A, true, 1, 1> : (dmv_fn)dmv3_kernel<A, false, 1, 1>) : (r16 ? (dmv_fn)dmv3_kernel<A, true, 1, 0> : (dmv_fn)dmv3_kernel<A, false, 1, 0>))
+        fn = k4 == WRK_MAT_Q4_K ? DMV3(WRK_MAT_Q4_K) : DMV3(WRK_MAT_Q5_K);
+#undef DMV3
+    }
+    else if (xi == 1) fn = pick_dmv_kind<1, 1>(ka, mixf, r16, pro);
     else if (xi == 2) fn = pick_dmv_kind<2, 1>(ka, mixf, r16, pro);
     else if (quant < 0 && xi <= 4) fn = pick_dmv_kind<4, 1>(ka, false, false, pro);          // F16 rows up to 2048 elements
     else if (!mixf && small_wg && pro == 0) fn = xi <= 4 ? pick_dmv_kind<1, 4>(ka, false, r16, 0) : pick_dmv_kind<2, 4>(ka, false, r16, 0);   // K over the 4 waves

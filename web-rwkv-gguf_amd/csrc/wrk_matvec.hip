@@ -721,7 +721,7 @@ static int launch_matvec(hipStream_t s, const MatvecParams& P, uint32_t total_wg
     matvec_fn fn = nullptr;
     bool needs_reg = false;     // fused prologue / state carry exist only in the register-input decode kernel
     for (int j = 0; j < P.njobs; ++j) needs_reg = needs_reg || P.jobs[j].pro || P.jobs[j].carry_dst || P.jobs[j].gate;
-    if (NB == 1 && tok_groups == 1 && nquant <= 1 && !mixed_r16 && launch_dmv(s, P, total_wg, nquant ? quant : -1, has_f16, r16, dry) == 0) return 0;
+    if (NB == 1 && tok_groups == 1 && nquant <= 2 && !mixed_r16 && launch_dmv(s, P, total_wg, nquant ? quant : -1, has_f16, r16, dry, nquant == 2 ? quant2 : -1) == 0) return 0;
     if (NB == 1 && tok_groups == 1 && nquant <= 2 && !mixed_r16) {
         fn = pick_reg(P, nquant ? quant : -1, has_f16, r16, nquant == 2 ? quant2 : -1);
         if (fn) {

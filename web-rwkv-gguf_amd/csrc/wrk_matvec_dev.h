@@ -387,6 +387,6 @@ __device__ __forceinline__ float dot_raw_reg(const Raw& r, uint32_t c, const XRe
 
 
 // wrk_dmv.hip: host side of the second-generation kernels; 0 = launched (or would be, dry), -1 = not eligible
-int launch_dmv(hipStream_t s, const MatvecParams& P, uint32_t total_wg, int quant, bool has_f16, bool r16, bool dry);
+int launch_dmv(hipStream_t s, const MatvecParams& P, uint32_t total_wg, int quant, bool has_f16, bool r16, bool dry, int quant2 = -1);
 
 }  // namespace wrk
