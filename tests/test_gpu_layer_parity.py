@@ -92,10 +92,11 @@ def run_case(ctx, name, weights, kw, mode, chunk_lens, steps):
     decode = all(n == 1 for n in chunk_lens)
     if mode == 0:
         table = MODE0
-    elif decode and T == 1:
-        # batch-1 decode: the split head kernel hands y = WKV output (pre group norm) and the gate to W_o's prologue
+    elif decode and T <= 8:
+        # 1 .. 8 sequences (the dmv kernels, 5 launches per layer): the split head kernel hands y = WKV output (pre group norm)
+        # and the gate to W_o's prologue
         table = [(b, "wkv" if b == "att_x" else k, d) for b, k, d in MODE1] + [("att_g", "g", False)]
-    elif decode:        # with several sequences LN + shifts run as their own launch and LN(x) is not stored separately
+    elif decode:        # with more sequences LN + shifts run as their own launch and LN(x) is not stored separately
         table = [e for e in MODE1 if e[0] not in ("att_x_ln", "ffn_x")]
     else:
         table = MERGED
@@ -140,8 +141,10 @@ def test_decode_layer_by_layer(ctx, name, weights, kw, mode):
 
 
 @pytest.mark.parametrize("mode", [0, 1])
-def test_two_sequences_decode_layer_by_layer(ctx, mode):
-    run_case(ctx, "tiny", wrk.WEIGHTS_INLINE, {}, mode, [1, 1], 4)        # multi-token matvec / MFMA launches of batched decode
+@pytest.mark.parametrize("nseq", [2, 3, 9])
+def test_several_sequences_decode_layer_by_layer(ctx, mode, nseq):
+    # 2, 3: the multi-token dmv launches (2- and 4-token instantiations; 3 leaves a clamped dead token); 9: the MFMA launches of batched decode
+    run_case(ctx, "tiny", wrk.WEIGHTS_INLINE, {}, mode, [1] * nseq, 3)
 
 
 @pytest.mark.parametrize("mode", [0, 1])

@@ -197,10 +197,13 @@ struct MatJob {
     float scale = 1.0f;                 // wrk_matrix::out_scale
     const void* gate = nullptr;         // f16 [M]: out = round(sigmoid(gate[row]) * round(act(W.x)))  (channel_mix.wgsl:104-106, RWKV-6), before the residual
     unsigned long long* dbg = nullptr;  // WRK_TIMING=1: 16 device timestamps of this launch (first and last workgroup)
+    // several input vectors (2 .. 4 sequences decoding together, dmv kernels): element strides from one token's operand to the next
+    uint32_t tok_prev_stride = 0, tok_mix_stride = 0, tok_carry_src_stride = 0, tok_carry_dst_stride = 0, tok_gate_stride = 0;
 };
 uint32_t matvec_num_wg(const MatJob* jobs, int njobs, int num_cu, uint32_t* rows_per_wg);
 // dry_run: classify only (0 = a launch would honour every job's prologue / carry request, -3 = it cannot)
-int matvec(hipStream_t s, const MatJob* jobs, int njobs, int num_cu, bool dry_run = false, bool no_catchall = false);
+// dmv_only: with 2 .. 4 input vectors, -5 unless the multi-token dmv kernels take the launch (the caller then prefers the matrix cores)
+int matvec(hipStream_t s, const MatJob* jobs, int njobs, int num_cu, bool dry_run = false, bool no_catchall = false, bool dmv_only = false);
 // as matvec, but jobs of several quantised kinds are split into one launch per kind (F16 jobs ride with the first)
 int matvec_grouped(hipStream_t s, const MatJob* jobs, int njobs, int num_cu, bool dry_run = false);
 // MFMA dequant-GEMM (wrk_gemm.hip); -2 = not applicable (caller uses the matvec kernels)

@@ -703,21 +703,28 @@ static matvec_fn pick_reg(const MatvecParams& P, int quant, bool has_f16, bool r
     return pick_reg_kernel<2, 4>(quant, quant, r16);                  // 8192 < K <= 16384
 }
 
-template <int NB>
-static int launch_matvec(hipStream_t s, const MatvecParams& P, uint32_t total_wg, uint32_t tok_groups, size_t smem, bool dry, bool no_catchall) {
-    // classify the kinds of this launch
-    int quant = -1, quant2 = -1, nquant = 0;
-    bool has_f16 = false, r16 = false, mixed_r16 = false;
+// the kinds of a launch
+struct KindMix { int quant = -1, quant2 = -1, nquant = 0; bool has_f16 = false, r16 = false, mixed_r16 = false; };
+static KindMix classify_kinds(const MatvecParams& P) {
+    KindMix c;
     for (int j = 0; j < P.njobs; ++j) {
         const int k = (int)P.jobs[j].kind;
-        if (k == WRK_MAT_F16) { has_f16 = true; continue; }
+        if (k == WRK_MAT_F16) { c.has_f16 = true; continue; }
         const bool jr = (P.jobs[j].flags & WRK_MATRIX_ROUND_F16) != 0;
-        if (nquant == 0) { quant = k; r16 = jr; nquant = 1; }
+        if (c.nquant == 0) { c.quant = k; c.r16 = jr; c.nquant = 1; }
         else {
-            if (k != quant && k != quant2) { quant2 = quant2 < 0 ? k : quant2; nquant = (k == quant2) ? 2 : 3; }
-            if (jr != r16) mixed_r16 = true;
+            if (k != c.quant && k != c.quant2) { c.quant2 = c.quant2 < 0 ? k : c.quant2; c.nquant = (k == c.quant2) ? 2 : 3; }
+            if (jr != c.r16) c.mixed_r16 = true;
         }
     }
+    return c;
+}
+
+template <int NB>
+static int launch_matvec(hipStream_t s, const MatvecParams& P, uint32_t total_wg, uint32_t tok_groups, size_t smem, bool dry, bool no_catchall) {
+    const KindMix c = classify_kinds(P);
+    const int quant = c.quant, quant2 = c.quant2, nquant = c.nquant;
+    const bool has_f16 = c.has_f16, r16 = c.r16, mixed_r16 = c.mixed_r16;
     matvec_fn fn = nullptr;
     bool needs_reg = false;     // fused prologue / state carry exist only in the register-input decode kernel
     for (int j = 0; j < P.njobs; ++j) needs_reg = needs_reg || P.jobs[j].pro || P.jobs[j].carry_dst || P.jobs[j].gate;
@@ -772,7 +779,7 @@ uint32_t matvec_num_wg(const MatJob* jobs, int njobs, int num_cu, uint32_t* rows
 }
 
 // All jobs of one call must have the same number of input vectors (T*B); they run in ONE launch.
-int matvec(hipStream_t s, const MatJob* jobs, int njobs, int num_cu, bool dry_run, bool no_catchall) {
+int matvec(hipStream_t s, const MatJob* jobs, int njobs, int num_cu, bool dry_run, bool no_catchall, bool dmv_only) {
     if (njobs <= 0 || njobs > MAX_JOBS) return -1;
     MatvecParams P;
     P.njobs = njobs;
@@ -795,6 +802,8 @@ int matvec(hipStream_t s, const MatJob* jobs, int njobs, int num_cu, bool dry_ru
         d.pro = jobs[j].pro; d.pro_eps = jobs[j].pro_eps; d.ln_w = (const f16*)jobs[j].ln_w; d.ln_b = (const f16*)jobs[j].ln_b;
         d.mixw = (const f16*)jobs[j].mixw; d.prev = jobs[j].prev; d.ln_out = (f16*)jobs[j].ln_out;
         d.carry_src = (const f16*)jobs[j].carry_src; d.carry_dst = jobs[j].carry_dst; d.gate = (const f16*)jobs[j].gate; d.scale = jobs[j].scale; d.dbg = jobs[j].dbg;
+        d.tok_prev_stride = jobs[j].tok_prev_stride; d.tok_mix_stride = jobs[j].tok_mix_stride; d.tok_carry_src_stride = jobs[j].tok_carry_src_stride;
+        d.tok_carry_dst_stride = jobs[j].tok_carry_dst_stride; d.tok_gate_stride = jobs[j].tok_gate_stride;
         wg += (jobs[j].m + d.rows_per_wg - 1) / d.rows_per_wg;
     }
     bool f32in = false;
@@ -806,6 +815,11 @@ int matvec(hipStream_t s, const MatJob* jobs, int njobs, int num_cu, bool dry_ru
         hipLaunchKernelGGL(matvec_f32in_kernel, dim3(wg, ntok), dim3(256), 0, s, P);
         return 0;
     }
+    if (ntok >= 2 && ntok <= 4) {       // a few sequences decoding together: the dmv kernels with 2 / 4 tokens per launch
+        const KindMix c = classify_kinds(P);
+        if (c.nquant <= 2 && !c.mixed_r16 && launch_dmv(s, P, wg, c.nquant ? c.quant : -1, c.has_f16, c.r16, dry_run, c.nquant == 2 ? c.quant2 : -1) == 0) return 0;
+    }
+    if (dmv_only && ntok > 1) return -5;
     const uint32_t kpad = (kmax + 15u) & ~15u;
     // pick inputs-per-pass: LDS budget 144 KiB
     int nb = ntok >= 8 ? 8 : (ntok >= 4 ? 4 : (ntok >= 2 ? 2 : 1));

@@ -105,6 +105,7 @@ struct JobDev {
     const f16* gate;
     float scale;
     unsigned long long* dbg;
+    uint32_t tok_prev_stride, tok_mix_stride, tok_carry_src_stride, tok_carry_dst_stride, tok_gate_stride;     // MatJob's
 };
 
 struct MatvecParams {

@@ -75,7 +75,7 @@ struct wrk_v7_model {
     // from_tokens: gather embedding rows of s.tokens on the device; want_argmax: greedy token per header row into
     // s.argmax; advance: also feed it back as the next token (device-resident generation loop)
     int32_t enqueue_fused_decode(wrk_v7_state* st, uint32_t B, uint32_t NH, bool identity_headers, bool from_tokens,
-                                 bool want_argmax, bool advance, uint32_t cursor0_batch);   // batch id of token 0 (used when T == 1)
+                                 bool want_argmax, bool advance, uint32_t cursor0_batch, bool contiguous);   // batch id of token 0; contiguous: token t is batch cursor0_batch + t
     void free_fused();
 };
 

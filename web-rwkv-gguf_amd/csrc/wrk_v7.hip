@@ -463,6 +463,9 @@ int32_t wrk_v7_infer(wrk_ctx* ctx, wrk_v7_model* m, wrk_v7_state* st, const uint
         if (len != 1) one_token_each = false;
         if (tokens) WRK_ARG(ctx, tokens[t] < V, "token %u: id %u >= vocab %u", t, tokens[t], V);
     }
+    // batches of consecutive tokens are consecutive: the few-sequence decode kernels address per-sequence state rows by a stride
+    bool contiguous = true;
+    for (uint32_t t = 1; t < T; ++t) contiguous = contiguous && (cursors[t] & 0xff) == (cursors[0] & 0xff) + t;
     bool identity = (NH == T);
     for (uint32_t h = 0; h < NH; ++h) {
         WRK_ARG(ctx, headers[h] < T, "header %u: row %u >= %u tokens", h, headers[h], T);
@@ -487,7 +490,7 @@ int32_t wrk_v7_infer(wrk_ctx* ctx, wrk_v7_model* m, wrk_v7_state* st, const uint
     // a 128-token chunk of one sequence is ~1 400 small launches, which replay at graph rate.
     auto enqueue_job = [&]() -> int32_t {
         int32_t r;
-        if (fused) r = m->enqueue_fused_decode(st, T, NH, identity, tokens != nullptr, NH && argmax, false, cursors[0] & 0xff);
+        if (fused) r = m->enqueue_fused_decode(st, T, NH, identity, tokens != nullptr, NH && argmax, false, cursors[0] & 0xff, contiguous);
         else {
             r = m->enqueue_ops(st, T, NH, identity, mode == 1);
             if (r == WRK_OK && NH && argmax) wrk::argmax_rows(ctx->op_stream(), m->s.head_o, V, V, NH, m->s.argmax);
@@ -499,7 +502,7 @@ int32_t wrk_v7_infer(wrk_ctx* ctx, wrk_v7_model* m, wrk_v7_state* st, const uint
     else {
         // bit 5: a non-fused job enqueues the merged launch list in mode 1 and the reference op list in mode 0 -- two graphs
         const uint32_t flags = 16u | (m->act_dtype == WRK_F32 ? 64u : 0u) | (fused ? 1u : 0u) | (identity ? 2u : 0u) | (tokens ? 4u : 0u) | ((NH && argmax) ? 8u : 0u) |
-                               ((!fused && mode == 1) ? 32u : 0u) | (fused ? (cursors[0] & 0xffu) << 8 : 0u);
+                               ((!fused && mode == 1) ? 32u : 0u) | (fused ? (cursors[0] & 0xffu) << 8 : 0u) | ((fused && contiguous) ? 1u << 16 : 0u);
         const wrk_v7_model::GraphKey key{st->uid, T, flags, NH};
         wrk_program* prog = nullptr;
         auto it = m->graphs.find(key);
@@ -569,6 +572,8 @@ int32_t wrk_v7_infer_layer(wrk_ctx* ctx, wrk_v7_model* m, wrk_v7_state* st, uint
         if (tok == t) { ++nseq; WRK_ARG(ctx, !seen[b], "cursor %u: batch %u twice", t, b); seen[b] = 1; }
         if (len != 1) one_token_each = false;
     }
+    bool contiguous = true;
+    for (uint32_t t = 1; t < T; ++t) contiguous = contiguous && (cursors[t] & 0xff) == (cursors[0] & 0xff) + t;
     int32_t rc = m->ensure_scratch(T, 1);
     if (rc != WRK_OK) return rc;
     const size_t esz = m->act_dtype == WRK_F32 ? 4 : 2;
@@ -577,7 +582,7 @@ int32_t wrk_v7_infer_layer(wrk_ctx* ctx, wrk_v7_model* m, wrk_v7_state* st, uint
     if (rc == WRK_OK && v_first) rc = wrk_buf_write_raw(ctx, m->s.att_v0, v_first, (size_t)T * m->d.num_emb * esz);
     if (rc != WRK_OK) return rc;
     m->layer_begin = layer; m->layer_end = layer + 1; m->skip_embed = true;
-    if (mode == 1 && one_token_each && nseq == T && m->act_dtype == WRK_F16) rc = m->enqueue_fused_decode(st, T, 0, true, false, false, false, cursors[0] & 0xff);
+    if (mode == 1 && one_token_each && nseq == T && m->act_dtype == WRK_F16) rc = m->enqueue_fused_decode(st, T, 0, true, false, false, false, cursors[0] & 0xff, contiguous);
     else rc = m->enqueue_ops(st, T, 0, true, mode == 1);
     m->layer_begin = 0; m->layer_end = 0xffffffffu; m->skip_embed = false;
     if (rc != WRK_OK) return rc;
@@ -638,7 +643,7 @@ static int32_t greedy_prepare(wrk_ctx* ctx, wrk_v7_model* m, wrk_v7_state* st, c
     if (it != m->graphs.end()) { *prog_out = it->second; return WRK_OK; }
     rc = wrk_capture_begin(ctx);
     if (rc != WRK_OK) return rc;
-    if (mode == 1 && m->act_dtype == WRK_F16) rc = m->enqueue_fused_decode(st, B, B, true, true, true, true, b0);
+    if (mode == 1 && m->act_dtype == WRK_F16) rc = m->enqueue_fused_decode(st, B, B, true, true, true, true, b0, true);
     else {
         wrk::gather_rows_f16(ctx->op_stream(), m->emb->ptr, m->s.tokens, m->s.input, D, B);
         rc = m->enqueue_ops(st, B, B, true);
@@ -711,7 +716,7 @@ int32_t wrk_v7_generate_greedy(wrk_ctx* ctx, wrk_v7_model* m, wrk_v7_state* st, 
         for (uint32_t i = 0; i < steps; ++i) {
             if (eager) {
                 int32_t rc;
-                if (mode == 1 && m->act_dtype == WRK_F16) rc = m->enqueue_fused_decode(st, B, B, true, true, true, true, 0);
+                if (mode == 1 && m->act_dtype == WRK_F16) rc = m->enqueue_fused_decode(st, B, B, true, true, true, true, 0, true);
                 else {
                     wrk::gather_rows_f16(ctx->op_stream(), m->emb->ptr, m->s.tokens, m->s.input, m->d.num_emb, B);
                     rc = m->enqueue_ops(st, B, B, true);

@@ -212,7 +212,7 @@ __global__ void __launch_bounds__(256) head_kernel(const HeadParams P) {
     if (P.shift_src && g4 == 1) shift = (float)P.shift_src[(size_t)t * D + c0 + i];
 
     // (2) state of this thread's column slice S[16*g4 .. +15][i]: needs the batch id; requested last, consumed last
-    const uint32_t batch = P.batch1 ? P.batch1 - 1 : (P.cursors[t] & 0xffu);
+    const uint32_t batch = P.batch1 ? P.batch1 - 1 + t : (P.cursors[t] & 0xffu);
     float* st = P.state + ((size_t)batch * (S + 2) + 1) * D + c0 + i;
     float Sreg[16];
 #pragma unroll
@@ -344,7 +344,7 @@ __global__ void __launch_bounds__(256) head_split_kernel(const HeadParams P, flo
     if (P.shift_src && tid < C) shift = (float)P.shift_src[(size_t)t * D + cq + tid];
 
     // (2) the state slice: thread (wave, lane = j) holds S[j][cq + 4*wave .. +3]; requested last, consumed last
-    const uint32_t batch = P.batch1 ? P.batch1 - 1 : (P.cursors[t] & 0xffu);
+    const uint32_t batch = P.batch1 ? P.batch1 - 1 + t : (P.cursors[t] & 0xffu);
     float* st = P.state + ((size_t)batch * (S + 2) + 1 + lane) * D + cq + 4 * wave;
     f32x4 Sv = *(const f32x4*)st;
 
@@ -539,7 +539,7 @@ static wrk::MatJob job(const wrk_matrix* m, DTensor in, DTensor out, uint32_t ac
 }
 
 int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_t NH, bool identity_headers, bool from_tokens,
-                                            bool want_argmax, bool advance, uint32_t cursor0_batch) {
+                                            bool want_argmax, bool advance, uint32_t cursor0_batch, bool contiguous) {
     using namespace wrk;
     hipStream_t q = ctx->op_stream();
     const uint32_t D = d.num_emb, F = d.num_hidden, H = d.num_head, S = D / H, V = d.num_vocab;
@@ -563,8 +563,9 @@ int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_
     }
     auto vec = [&](void* p, uint32_t c = 0) { return make_dense(p, WRK_F16, c ? c : D, T); };
     // batched decode (many sequences): each matrix goes to the MFMA GEMM; few sequences: one multi-matrix matvec launch
+    bool single = false;        // this layer runs the 5-launch structure (prologue-fused dmv kernels)
     auto run_jobs = [&](MatJob* jobs, int n) -> int {
-        if (T >= gemm_min_tokens()) {
+        if (!single && T >= gemm_min_tokens()) {
             if (matmul_mfma_multi(q, jobs, n, ctx->num_cu) == 0) return 0;      // all matrices of the stage in one launch
             for (int i = 0; i < n; ++i) {
                 int rc = matmul_mfma(q, jobs[i], ctx->num_cu);
@@ -596,7 +597,10 @@ int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_
         // instead of 7; 0.865 vs 0.963 ms/token on MI355X, round 1).  The prologue lives in the register-input kernels
         // only: a dry run of the three launches decides per layer; WRK_FUSE_LN=0 forces the 7-launch path.
         static const bool fuse_ln = [] { const char* e = getenv("WRK_FUSE_LN"); return !(e && e[0] == '0'); }();
-        bool single = fuse_ln && (T == 1) && D <= 4096;
+        // 2 .. 4 sequences (round 2): the same structure on the dmv kernels' multi-token instantiations when the sequences' state
+        // rows are a constant stride apart (token t = batch cursor0_batch + t, host-checked); WRK_DMV_TOKENS=1 restores the MFMA path
+        static const uint32_t few_max = [] { const char* e = getenv("WRK_DMV_TOKENS"); const int v = e ? atoi(e) : 4; return (uint32_t)(v < 1 ? 1 : (v > 4 ? 4 : v)); }();
+        single = fuse_ln && (T == 1 || (T <= few_max && contiguous)) && D <= 4096;
         if (single) {
             MatJob k1[7] = {job(L.w_r, vec(s.x), vec(s.r), 0), job(L.w_k, vec(s.x), vec(s.k), 0), job(L.w_v, vec(s.x), vec(s.v), 0),
                             job(L.w1, vec(s.x), vec(s.aux_w, d.lora_w), 0), job(L.a1, vec(s.x), vec(s.aux_a, d.lora_a), 0),
@@ -605,12 +609,14 @@ int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_
             MatJob k5 = job(L.ffn_w_k, vec(s.x), vec(s.ffn_k, F), 0);
             k5.pro = 1;
             MatJob k6 = job(L.ffn_w_v, vec(s.ffn_k, F), vec(s.x), 0);
+            k6.has_res = 1; k6.res = vec(s.x);
             k6.carry_dst = (float*)s.x;     // any non-null pointer: classification only
             single = matvec_grouped(q, k1, li ? 7 : 6, ctx->num_cu, true) == 0 && matvec(q, &k5, 1, ctx->num_cu, true) == 0 &&
                      matvec(q, &k6, 1, ctx->num_cu, true) == 0;
         }
         // split head (4 workgroups per head, group norm in W_o's prologue): batch-1 decode whose W_o launch the dmv kernels take
         static const bool want_split = [] { const char* e = getenv("WRK_SPLIT_HEAD"); return !(e && e[0] == '0'); }();
+        const uint32_t state_stride = (S + 2) * D;       // floats between the state rows of consecutive sequences
         bool split_head = want_split && single && d.lora_w >= 8 && d.lora_a >= 8 && d.lora_g >= 8 && d.lora_v >= 8 && d.lora_g <= 512;
         if (split_head) {
             MatJob k3 = job(L.w_o, vec(s.att_x), vec(s.x), 0);
@@ -645,7 +651,7 @@ int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_
                 for (int i = 0; i < 7; ++i) {
                     jobs[i].in = vec(s.x);
                     jobs[i].pro = 1; jobs[i].pro_eps = 1.0e-5f; jobs[i].ln_w = L.ln1_w->ptr; jobs[i].ln_b = L.ln1_b->ptr;
-                    jobs[i].mixw = mx[i]->ptr; jobs[i].prev = row0;
+                    jobs[i].mixw = mx[i]->ptr; jobs[i].prev = row0; jobs[i].tok_prev_stride = state_stride;
                 }
                 jobs[0].ln_out = s.ln_tmp;      // LN(x): becomes the att shift state in K2
             }
@@ -668,7 +674,7 @@ int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_
             P.v_first = (f16*)s.att_v0; P.out = (f16*)s.att_x;
             P.state = lst; P.cursors = s.cursors; P.gn_eps = 64.0e-5f; P.l2_eps = 1.0e-12f;
             P.shift_src = single ? (const f16*)s.ln_tmp : nullptr;     // fused K0: the state carry happens here
-            P.batch1 = single ? batch0 + 1 : 0;
+            P.batch1 = single ? batch0 + 1 : 0;                         // token t is batch batch0 + t
             P.dbg = li == TIMED_LAYER ? wrk::timing_slot(ctx, "K2 head: LoRA-2 + WKV7 + group norm") : nullptr;
             if (split_head) {
                 if (d.lora_g <= 256) head_split_kernel<2><<<dim3(H * 4, T), 256, 0, q>>>(P, (float*)s.n, (f16*)s.g, H);
@@ -682,6 +688,7 @@ int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_
             j.has_res = 1; j.res = vec(s.x);
             if (split_head) {       // group norm + time_first + gate of the split head kernel's hand-over, in the prologue
                 j.pro = 2; j.pro_eps = 64.0e-5f; j.ln_w = L.gn_w->ptr; j.ln_b = L.gn_b->ptr; j.mixw = s.g; j.prev = (const float*)s.n;
+                j.tok_mix_stride = D; j.tok_prev_stride = D;
             }
             if (li == TIMED_LAYER) j.dbg = wrk::timing_slot(ctx, "K3 w_o + residual");
             if (run_jobs(&j, 1) != 0) return wrk_fail(ctx, WRK_E_ARG, "fused K3 rejected");
@@ -699,6 +706,7 @@ int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_
             if (single) {
                 j.in = vec(s.x);
                 j.pro = 1; j.pro_eps = 1.0e-5f; j.ln_w = L.ln2_w->ptr; j.ln_b = L.ln2_b->ptr; j.mixw = L.ffn_x_k->ptr; j.prev = rowf;
+                j.tok_prev_stride = state_stride;
                 j.ln_out = s.ffn_x;             // LN(x): becomes the ffn shift state in K6's epilogue
             }
             if (li == TIMED_LAYER) j.dbg = wrk::timing_slot(ctx, "K5 ffn key (LN2 prologue)");
@@ -707,7 +715,7 @@ int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_
         {   // K6: x += W_v . relu(k)^2
             MatJob j = job(L.ffn_w_v, vec(s.ffn_k, F), vec(s.x), WRK_ACT_NONE);
             j.has_res = 1; j.res = vec(s.x);
-            if (single) { j.carry_src = s.ffn_x; j.carry_dst = rowf; }
+            if (single) { j.carry_src = s.ffn_x; j.carry_dst = rowf; j.tok_carry_src_stride = D; j.tok_carry_dst_stride = state_stride; }
             if (li == TIMED_LAYER) j.dbg = wrk::timing_slot(ctx, "K6 ffn value + residual");
             if (run_jobs(&j, 1) != 0) return wrk_fail(ctx, WRK_E_ARG, "fused K6 rejected");
         }
@@ -722,8 +730,15 @@ int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_
         LN(P, NH);
         MatJob j = job(head, make_dense(s.head_x, WRK_F16, D, NH), make_dense(s.head_o, WRK_F32, V, NH), WRK_ACT_NONE);
         uint32_t nwg = 0;
+        // a few header rows: the multi-token dmv kernel streams the head once for all of them, arg-max partials fused
+        bool head_mv = NH < gemm_min_tokens();
+        if (!head_mv && NH <= 4) {
+            MatJob probe = j;
+            if (want_argmax) { probe.amax_val = amax_val; probe.amax_idx = amax_idx; }
+            head_mv = (size_t)matvec_num_wg(&j, 1, ctx->num_cu, nullptr) * NH <= amax_cap && matvec(q, &probe, 1, ctx->num_cu, true, false, true) == 0;
+        }
         // several header rows: the head goes to the matrix cores too and the arg-max becomes its own (tiny) kernel
-        if (NH >= gemm_min_tokens() && matmul_mfma(q, j, ctx->num_cu) == 0) {
+        if (!head_mv && matmul_mfma(q, j, ctx->num_cu) == 0) {
             if (want_argmax) {
                 wrk::argmax_rows(q, (const float*)s.head_o, V, V, NH, s.argmax);
                 if (advance) wrk::advance_tokens(q, s.argmax, s.tokens, history, s.counter, NH);
