@@ -85,6 +85,25 @@ struct GemmBatch {
 // token index -> (t, b) of the [C, T, B] views
 __device__ __forceinline__ void tok_tb(const DTensor& d, uint32_t tok, uint32_t& t, uint32_t& b) { t = tok % d.shape[1]; b = tok / d.shape[1]; }
 
+// Residual operands of the C elements a lane stores: raw bits, requested with the first loads of the kernel.  UNCONDITIONAL: a launch
+// without residual (or with the other element type) reads a mapped dummy (the first activations).  The branchy form
+// (`if (has_res) { if (res32) load4 else load2 }`) made the compiler wait `vmcnt(0)` at the join -- in the K-sliced kernel that was the whole
+// weight burst before the activations could be staged, in the K-split kernel one extra round trip at the head of W_o / ffn.value.
+template <int NT>
+__device__ __forceinline__ void load_residual(const GemmParams& P, uint32_t n0, uint32_t m0, uint32_t r, uint32_t g, uint32_t (&resb)[NT][4]) {
+    const bool r32 = P.has_res && P.res32, r16b = P.has_res && !P.res32;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const size_t ro = (size_t)min(n0 + 16 * t + r, P.n - 1) * P.rs + min(m0 + 4 * g, P.m - 4u);
+        const u32x4 v4 = *(const u32x4*)(r32 ? (const void*)((const float*)P.res_p + ro) : (const void*)P.x);
+        const u32x2 v2 = *(const u32x2*)(r16b ? (const void*)((const f16*)P.res_p + ro) : (const void*)P.x);
+        resb[t][0] = r32 ? v4.x : (v2.x & 0xffffu);
+        resb[t][1] = r32 ? v4.y : (v2.x >> 16);
+        resb[t][2] = r32 ? v4.z : (v2.y & 0xffffu);
+        resb[t][3] = r32 ? v4.w : (v2.y >> 16);
+    }
+}
+
 // Round 2: every global load of this kernel is UNCONDITIONAL (token, row, block and k indices are clamped; dead blocks are
 // multiplied by zero scales, dead token columns are never stored) and every wave of a workgroup runs the same trip count.
 // The first version predicated its loads (`live ? load : zero`, `if (u < nmine) load_w`); the compiler then loses count of
@@ -119,14 +138,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& P, float (*sh_tot)[N
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int i = 0; i < 4; ++i) resb[t][i] = 0;
-    if (P.has_res) {        // uniform
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const size_t ro = (size_t)min(n0 + 16 * t + r, P.n - 1) * P.rs + min(m0 + 4 * g, P.m - 4u);
-            if (P.res32) { const u32x4 v = *(const u32x4*)((const float*)P.res_p + ro); resb[t][0] = v.x; resb[t][1] = v.y; resb[t][2] = v.z; resb[t][3] = v.w; }
-            else { const u32x2 v = *(const u32x2*)((const f16*)P.res_p + ro); resb[t][0] = v.x & 0xffffu; resb[t][1] = v.x >> 16; resb[t][2] = v.y & 0xffffu; resb[t][3] = v.y >> 16; }
-        }
-    }
+    load_residual<NT>(P, n0, m0, r, g, resb);
 
     if (KIND == WRK_MAT_F16) {
         // this wave's 32-k steps are wave, wave + NW, ...; FB steps' fragments are requested together.  Steps beyond K are
@@ -1092,6 +1104,240 @@ __global__ void __launch_bounds__(256) gemm_dec_kernel(const GemmBatch B) {
     else gemm_dec_body<WRK_MAT_Q5_K>(P, dec_smem);
 }
 
+// ------------------------------------------------------------------ K-sliced GEMM for decode batches (5 .. 32 stacked tokens; round 2)
+// What the in-kernel timelines of batched decode showed: a CU ingests only ~30 GB/s when its loads are one
+// dependent burst (outstanding misses x latency), and the kernels above make every workgroup pull the WHOLE activation stack -- 64 KB at
+// 16 tokens, 256 KB at 64 -- next to 5-18 KB of weights; ffn.value (2048 rows, K = 8192) ran 13.8 us at 16 tokens and 23 us at 32 / 64 on
+// HALF the chip.  Here a workgroup owns 64 rows x a SLICE of K (BPS 256-blocks): its 4 waves take 16 rows each, the slice of the
+// activations (tokens x BPS*256) is staged ONCE through LDS with coalesced loads, every global load of the kernel is issued up front and
+// unconditionally.  K slices of a row group meet through f32 partial tiles in a scratch buffer: each slice stores its tile, releases,
+// and bumps the row group's counter; the LAST arriver acquires, adds the tiles in slice order (so the sum does not depend on who is
+// last), applies scale / activation / residual and stores, and resets the counter for the next launch.  Per workgroup ingest at 16 tokens,
+// K = 2048, BPS = 2: 18 KB of weights + 16 KB of activations.
+struct KsJob {
+    uint32_t nslices, rg_begin;     // K slices per row group; first row group of this job in the counter / partial space
+};
+struct KsBatch {
+    GemmBatch g;
+    KsJob ks[GEMM_MAX_JOBS];
+    float* part;                    // [row group][slice][token (ntp)][64 rows] f32
+    uint32_t* counters;             // [row group], zero between launches
+    uint32_t ntp;                   // tokens padded to the tile: 16 * NT
+};
+
+template <int KIND, int NT, int BPS>
+__device__ __forceinline__ void gemm_ks_body(const GemmParams& P, const KsJob& E, float* __restrict__ part, uint32_t* __restrict__ counters,
+                                             f16* __restrict__ lds, uint32_t* sh_flag) {
+    constexpr uint32_t ROWF = BPS * 256 + 8;            // f16 per staged token row (+16 B: the 16 token rows of a fragment read hit distinct banks)
+    constexpr uint32_t CPT = BPS * 32;                  // 16-byte chunks per token and slice
+    constexpr int NST = 2 * NT * BPS;                   // chunks each thread stages
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const uint32_t r = lane & 15, g = lane >> 4;
+    const uint32_t local = blockIdx.x - P.wg_begin;
+    const uint32_t rg = local / E.nslices, z = local - rg * E.nslices;
+    const uint32_t m0 = rg * 64 + wave * 16;
+    const uint32_t K = P.k, nb = K >> 8;
+    const uint32_t b0 = z * BPS;                        // host: nslices * BPS == nb
+    WRK_STAMP(P.dbg, 0);
+    const uint32_t row = min(m0 + r, P.m - 1);
+    const uint8_t* wrow = P.w + (size_t)row * P.row_bytes;
+
+    // ---- every global load of the kernel, back to back: activations of the slice, weights of the slice, residual operands
+    f16x8 stage[NST];
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+        const uint32_t c = tid + 256u * i, tok = c / CPT, ch = c % CPT;
+        stage[i] = *(const f16x8*)(P.x + (size_t)min(tok, P.n - 1) * P.xs + (size_t)b0 * 256 + ch * 8);
+    }
+    struct WBlk { u32x2 q[4]; u32x2 qh; u32x4 sm; uint32_t dd[4]; };
+    WBlk W[KIND == WRK_MAT_F16 ? 1 : BPS];
+    f16x8 WF[KIND == WRK_MAT_F16 ? BPS : 1][8];
+    if (KIND == WRK_MAT_F16) {
+        const f16* wr = (const f16*)wrow;
+#pragma unroll
+        for (int u = 0; u < BPS; ++u)
+#pragma unroll
+            for (int sb = 0; sb < 8; ++sb) WF[u][sb] = *(const f16x8*)(wr + (size_t)(b0 + u) * 256 + sb * 32 + 8 * g);
+    } else {
+        const uint32_t hoff = KIND == WRK_MAT_Q4_K ? nb * 128 : nb * 160, soff = hoff + nb * 4;
+        const uint8_t* crow[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) crow[i] = P.w + (size_t)min(m0 + 4 * g + i, P.m - 1) * P.row_bytes + hoff;
+#pragma unroll
+        for (int u = 0; u < BPS; ++u) {
+            const uint32_t b = b0 + u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) W[u].q[j] = *(const u32x2*)(wrow + (size_t)b * 128 + j * 32 + 8 * g);
+            if (KIND == WRK_MAT_Q5_K) W[u].qh = *(const u32x2*)(wrow + (size_t)nb * 128 + (size_t)b * 32 + 8 * g);
+            W[u].sm = *(const u32x4*)(wrow + soff + (size_t)b * 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) W[u].dd[i] = *(const uint32_t*)(crow[i] + (size_t)b * 4);
+        }
+    }
+    uint32_t resb[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) resb[t][i] = 0;
+    load_residual<NT>(P, 0, m0, r, g, resb);
+    // ---- the activation slice, once per workgroup, through LDS
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+        const uint32_t c = tid + 256u * i, tok = c / CPT, ch = c % CPT;
+        *(f16x8*)(lds + tok * ROWF + ch * 8) = stage[i];
+    }
+    __syncthreads();
+    WRK_STAMP(P.dbg, 1);
+
+    f32x4v total[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) total[t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+    const f16* xt = lds + r * ROWF + 8 * g;             // B fragment of token tile t, block u, sub-block sb: xt + 16 t ROWF + 256 u + 32 sb
+#pragma unroll
+    for (int u = 0; u < BPS; ++u) {
+        if (KIND == WRK_MAT_F16) {
+#pragma unroll
+            for (int sb = 0; sb < 8; ++sb)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) total[t] = mfma16(WF[u][sb], *(const f16x8*)(xt + 16 * t * ROWF + 256 * u + 32 * sb), total[t]);
+        } else {
+            const WBlk& R = W[KIND == WRK_MAT_F16 ? 0 : u];
+            f32x4v acc[NT], amin[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { acc[t] = (f32x4v){0.f, 0.f, 0.f, 0.f}; amin[t] = (f32x4v){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const u32x2 q = R.q[j];
+                const uint32_t v = R.sm[j];
+                const float sc0 = (float)(v & 0xffu), sc1 = (float)((v >> 8) & 0xffu);
+                f16x8 alo, ahi;
+                if (KIND == WRK_MAT_Q4_K) {
+                    alo = mul8(codes8(q.x & 0x0f0f0f0fu, q.y & 0x0f0f0f0fu), sc0 * 1024.0f);          // q*sc*2^-14
+                    ahi = mul8(codes8(q.x & 0xf0f0f0f0u, q.y & 0xf0f0f0f0u), sc1 * 64.0f);            // (16q)*sc*2^-18
+                } else {
+                    const uint32_t s0 = 2 * j, s1 = 2 * j + 1;
+                    alo = mul8(codes8((q.x & 0x0f0f0f0fu) | (((R.qh.x >> s0) & 0x01010101u) << 4), (q.y & 0x0f0f0f0fu) | (((R.qh.y >> s0) & 0x01010101u) << 4)), sc0 * 1024.0f);
+                    ahi = mul8(codes8(((q.x >> 4) & 0x0f0f0f0fu) | (((R.qh.x >> s1) & 0x01010101u) << 4), ((q.y >> 4) & 0x0f0f0f0fu) | (((R.qh.y >> s1) & 0x01010101u) << 4)), sc1 * 1024.0f);
+                }
+                const f16 m0h = (f16)(float)((v >> 16) & 0xffu), m1h = (f16)(float)(v >> 24);
+                const f16x8 mlo = {m0h, m0h, m0h, m0h, m0h, m0h, m0h, m0h}, mhi = {m1h, m1h, m1h, m1h, m1h, m1h, m1h, m1h};
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const f16x8 bq0 = *(const f16x8*)(xt + 16 * t * ROWF + 256 * u + 64 * j);
+                    const f16x8 bq1 = *(const f16x8*)(xt + 16 * t * ROWF + 256 * u + 64 * j + 32);
+                    acc[t] = mfma16(alo, bq0, acc[t]);
+                    acc[t] = mfma16(ahi, bq1, acc[t]);
+                    amin[t] = mfma16(mlo, bq0, amin[t]);
+                    amin[t] = mfma16(mhi, bq1, amin[t]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float d = (float)__builtin_bit_cast(f16, (uint16_t)(R.dd[i] & 0xffffu)) * 16384.0f;
+                const float dmin = (float)__builtin_bit_cast(f16, (uint16_t)(R.dd[i] >> 16));
+#pragma unroll
+                for (int t = 0; t < NT; ++t) total[t][i] += d * acc[t][i] - dmin * amin[t][i];
+            }
+        }
+    }
+    WRK_STAMP(P.dbg, 2);
+
+    // ---- K slices meet: partial tile out, count, the last arriver adds them up in slice order
+    if (E.nslices > 1) {
+        const size_t tile = (size_t)16 * NT * 64;                              // floats per (row group, slice)
+        float* p0 = part + (size_t)(E.rg_begin + rg) * E.nslices * tile;
+        // Agent-scope coherence PER ACCESS (sc1 write-through stores, sc1 loads, an sc1 counter), not cache-wide fences: the first version
+        // used release / acquire fences (buffer_wbl2 + buffer_inv per workgroup) and ran 4x SLOWER than the kernels it replaces -- every
+        // workgroup wrote back and invalidated its XCD's whole L2, activations included.  Order: this wave's tile stores are performed
+        // (vmcnt(0)) before the workgroup barrier, the counter is bumped after it; the last arriver's loads are issued after it has seen
+        // the count.
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float* pp = p0 + (size_t)z * tile + (size_t)(16 * t + r) * 64 + wave * 16 + 4 * g;
+            // one 16-byte write-through store per tile.  The s_nop covers the VMEM-store-data hazard (a store of more than 8 bytes followed
+            // by a VALU write of its data registers): the compiler's hazard pass does not look inside an asm statement
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" ::"v"(pp), "v"(total[t]) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) *sh_flag = __hip_atomic_fetch_add(counters + E.rg_begin + rg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (*sh_flag != E.nslices - 1) return;                                 // uniform over the workgroup
+        if (tid == 0) __hip_atomic_store(counters + E.rg_begin + rg, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        WRK_STAMP(P.dbg, 3);
+        // all partial tiles of the row group in ONE round trip: up to PF slices x NT vector loads in flight, added in slice order
+        constexpr int PF = NT == 1 ? 8 : 4;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) total[t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+        for (uint32_t z0 = 0; z0 < E.nslices; z0 += PF) {
+            f32x4v pv[PF][NT];
+            const float* pa[PF][NT];
+#pragma unroll
+            for (int u = 0; u < PF; ++u)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) pa[u][t] = p0 + (size_t)min(z0 + u, E.nslices - 1) * tile + (size_t)(16 * t + r) * 64 + wave * 16 + 4 * g;
+            // eight agent-scope vector loads and their wait in ONE statement: the compiler cannot see that an asm load completes later, so
+            // the values may only leave the statement once they have arrived (separate load / wait statements let it copy a register early)
+            static_assert(PF * NT == 8, "eight loads per statement");
+            f32x4v(&pf)[8] = *reinterpret_cast<f32x4v(*)[8]>(&pv[0][0]);
+            const float* const(&af)[8] = *reinterpret_cast<const float* const(*)[8]>(&pa[0][0]);
+            asm volatile(
+                "global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %9, off sc1\n\tglobal_load_dwordx4 %2, %10, off sc1\n\t"
+                "global_load_dwordx4 %3, %11, off sc1\n\tglobal_load_dwordx4 %4, %12, off sc1\n\tglobal_load_dwordx4 %5, %13, off sc1\n\t"
+                "global_load_dwordx4 %6, %14, off sc1\n\tglobal_load_dwordx4 %7, %15, off sc1\n\ts_waitcnt vmcnt(0)"
+                : "=&v"(pf[0]), "=&v"(pf[1]), "=&v"(pf[2]), "=&v"(pf[3]), "=&v"(pf[4]), "=&v"(pf[5]), "=&v"(pf[6]), "=&v"(pf[7])
+                : "v"(af[0]), "v"(af[1]), "v"(af[2]), "v"(af[3]), "v"(af[4]), "v"(af[5]), "v"(af[6]), "v"(af[7])
+                : "memory");
+#pragma unroll
+            for (int u = 0; u < PF; ++u)
+                if (z0 + u < E.nslices)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) total[t] += pv[u][t];
+        }
+    }
+
+    // store: lane owns rows m0 + 4g + (0..3) of token column r of each tile
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const uint32_t tok = 16 * t + r;
+        if (tok >= P.n) continue;
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            o[i] = act_apply(P.act, total[t][i] * P.scale);
+            if (P.has_res) o[i] = (P.out32 ? o[i] : r16(o[i])) + (P.res32 ? __builtin_bit_cast(float, resb[t][i]) : (float)__builtin_bit_cast(f16, (uint16_t)resb[t][i]));
+        }
+        const size_t oo = (size_t)tok * P.os + m0 + 4 * g;
+        if (m0 + 4 * g + 4 <= P.m) {
+            if (P.out32) *(f32x4v*)((float*)P.out_p + oo) = (f32x4v){o[0], o[1], o[2], o[3]};
+            else { typedef _Float16 f16x4 __attribute__((ext_vector_type(4))); *(f16x4*)((f16*)P.out_p + oo) = (f16x4){(f16)o[0], (f16)o[1], (f16)o[2], (f16)o[3]}; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (m0 + 4 * g + i < P.m) { if (P.out32) ((float*)P.out_p)[oo + i] = o[i]; else ((f16*)P.out_p)[oo + i] = (f16)o[i]; }
+        }
+    }
+    WRK_STAMP(P.dbg, 4);
+}
+
+template <int NT, int BPS>
+__global__ void __launch_bounds__(256) gemm_ks_kernel(const KsBatch B) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ks_smem[];
+    __shared__ uint32_t sh_flag;
+    int ji = 0;
+#pragma unroll
+    for (int q = 1; q < GEMM_MAX_JOBS; ++q)
+        if (q < B.g.njobs && blockIdx.x >= B.g.jobs[q].wg_begin) ji = q;
+    const GemmParams& P = B.g.jobs[ji];
+    f16* lds = (f16*)ks_smem;
+    switch (P.kind) {
+        case WRK_MAT_Q4_K: gemm_ks_body<WRK_MAT_Q4_K, NT, BPS>(P, B.ks[ji], B.part, B.counters, lds, &sh_flag); break;
+        case WRK_MAT_Q5_K: gemm_ks_body<WRK_MAT_Q5_K, NT, BPS>(P, B.ks[ji], B.part, B.counters, lds, &sh_flag); break;
+        default: gemm_ks_body<WRK_MAT_F16, NT, BPS>(P, B.ks[ji], B.part, B.counters, lds, &sh_flag); break;
+    }
+}
+
 // fewest stacked tokens sent to the matrix cores (tiles are padded to 16 tokens; below this the matvec kernels run)
 uint32_t gemm_min_tokens() {
     static const uint32_t v = [] { const char* e = getenv("WRK_GEMM_MIN"); const int x = e ? atoi(e) : 2; return (uint32_t)(x < 2 ? 2 : x); }();     // measured (1.5B decode): 2 sequences break even, 3: 1.33 vs 1.79 ms, 8: 2x in favour of MFMA
@@ -1135,11 +1381,83 @@ static void fill_job(GemmParams& P, const MatJob& j, uint32_t n, uint32_t wg_beg
     P.levels = (const float*)j.aux;
 }
 
+// the K-sliced kernel: 0 = launched, -1 = not applicable (the caller continues with the other kernels)
+static int launch_ks(hipStream_t s, const MatJob* jobs, int njobs, uint32_t n) {
+    // Measured (1.5B Q4_K_M decode, ms per step: K-split kernels | this kernel for ffn.value only | for every launch; profiles/r02_ks_modes.txt):
+    //   5 seq 1.265 | 1.222 | 1.382    8: 1.319 | 1.251 | 1.391    16: 1.498 | 1.390 | 1.468    24: 1.962 | 1.899 | 1.877
+    //   32: 2.158 | 2.044 | 1.967      48: 3.150 | 3.981 | 3.803   64: 3.474 | 4.295 | 4.011
+    // -> up to 16 tokens only the launch with few row tiles and long rows (ffn.value: 2048 rows x K = 8192, 13.8 -> 8.7 us at 16 tokens),
+    // 17 .. 32 tokens every eligible launch, beyond that none (a 64-token slice is 32 KB per 256-block: the ingest problem again).
+    // Each phase of the kernel is one memory round trip of ~2 us under load (stage | weights | tile out + count | tiles in), which is why it
+    // only wins where the K-split kernel needs four dependent block iterations.  WRK_GEMM_KS: 0 off | 1 as above | 2 every eligible launch.
+    // (read per call, not once per process: the tests switch it; launches are captured into graphs, so this is off the replay path)
+    const char* mode_env = getenv("WRK_GEMM_KS");
+    const int mode = mode_env ? atoi(mode_env) : 1;
+    if (mode <= 0 || !jobs[0].ks_part || !jobs[0].ks_cnt || n > 32) return -1;
+    const int nt = n <= 16 ? 1 : 2;
+    if (mode == 1 && n <= 16) {
+        uint32_t tiles16 = 0, kmax = 0;
+        for (int q = 0; q < njobs; ++q) { tiles16 += (jobs[q].m + 15) / 16; kmax = jobs[q].k > kmax ? jobs[q].k : kmax; }
+        if (!(tiles16 < 256 && kmax >= 4096)) return -1;
+    }
+    for (int q = 0; q < njobs; ++q) {
+        const MatJob& j = jobs[q];
+        if (j.kind != WRK_MAT_Q4_K && j.kind != WRK_MAT_Q5_K && j.kind != WRK_MAT_F16) return -1;
+        if ((j.k & 255u) || j.k < 256) return -1;
+    }
+    // blocks per slice: as many as still give every CU a workgroup (fewer slices = fewer partial tiles to add); the staged activation
+    // slice (16 nt tokens x bps x 256) has to fit the default 64 KB of dynamic LDS
+    static const int force_bps = [] { const char* e = getenv("WRK_KS_BPS"); return e ? atoi(e) : 0; }();
+    int bps = 0;
+    for (int cand = 4; cand >= 1 && !bps; cand >>= 1) {
+        if (nt * cand > 4) continue;
+        if (force_bps && cand != force_bps) continue;
+        bool div = true;
+        uint32_t wgs = 0;
+        for (int q = 0; q < njobs; ++q) { const uint32_t nb = jobs[q].k >> 8; div = div && nb % cand == 0; wgs += ((jobs[q].m + 63) / 64) * (nb / cand); }
+        if (div && (wgs >= 256 || cand == 1 || force_bps)) bps = cand;
+    }
+    if (!bps) return -1;
+    KsBatch B;
+    B.g.njobs = njobs;
+    B.part = jobs[0].ks_part; B.counters = jobs[0].ks_cnt; B.ntp = 16u * nt;
+    uint32_t wg = 0, rg0 = 0;
+    size_t floats = 0;
+    for (int q = 0; q < njobs; ++q) {
+        const uint32_t nsl = (jobs[q].k >> 8) / bps, nrg = (jobs[q].m + 63) / 64;
+        if (nsl > 64) return -1;
+        fill_job(B.g.jobs[q], jobs[q], n, wg);
+        B.ks[q].nslices = nsl; B.ks[q].rg_begin = rg0;
+        wg += nrg * nsl; rg0 += nrg;
+        floats += (size_t)nrg * nsl * 64 * 16 * nt;
+    }
+    // (row groups of one job are contiguous in the partial space: rg_begin counts row groups, the slices of a group sit side by side,
+    // so the partial offset of job q is rg_begin x nslices_q tiles only when all jobs share nslices -- they do: one bps, and K differs
+    // only between launches; checked here)
+    for (int q = 1; q < njobs; ++q)
+        if (B.ks[q].nslices != B.ks[0].nslices) return -1;
+    if (floats > jobs[0].ks_part_cap || rg0 > jobs[0].ks_cnt_cap) return -1;
+    const size_t smem = (size_t)16 * nt * (bps * 256 + 8) * sizeof(f16);
+#define KS_LAUNCH(NT_, BPS_)                                                                                                              \
+    do {                                                                                                                                  \
+        if (smem > 64 * 1024) {                                                                                                           \
+            static bool done = false;                                                                                                     \
+            if (!done) { if (hipFuncSetAttribute((const void*)gemm_ks_kernel<NT_, BPS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -1; done = true; } \
+        }                                                                                                                                 \
+        gemm_ks_kernel<NT_, BPS_><<<dim3(wg), 256, smem, s>>>(B);                                                                         \
+    } while (0)
+    if (nt == 1) { if (bps == 4) KS_LAUNCH(1, 4); else if (bps == 2) KS_LAUNCH(1, 2); else KS_LAUNCH(1, 1); }
+    else { if (bps == 2) KS_LAUNCH(2, 2); else KS_LAUNCH(2, 1); }
+#undef KS_LAUNCH
+    return 0;
+}
+
 int matmul_mfma_multi(hipStream_t s, const MatJob* jobs, int njobs, int) {
     if (njobs <= 0 || njobs > GEMM_MAX_JOBS) return -2;
     const uint32_t n = jobs[0].in.shape[1] * jobs[0].in.shape[2];
     for (int j = 0; j < njobs; ++j)
         if (!gemm_ok(jobs[j], n)) return -2;
+    if (launch_ks(s, jobs, njobs, n) == 0) return 0;
     // prefill regime: Q4_K / Q5_K / Q6_K / F16 matrices with >= 64 rows go to the LDS-tiled kernel, the rest (Q8_0, Int8, short)
     // to the K-split kernel, each group in one launch
     static const bool use_tile = [] { const char* e = getenv("WRK_GEMM_TILE"); return !(e && e[0] == '0'); }();

@@ -199,6 +199,12 @@ struct MatJob {
     unsigned long long* dbg = nullptr;  // WRK_TIMING=1: 16 device timestamps of this launch (first and last workgroup)
     // several input vectors (2 .. 4 sequences decoding together, dmv kernels): element strides from one token's operand to the next
     uint32_t tok_prev_stride = 0, tok_mix_stride = 0, tok_carry_src_stride = 0, tok_carry_dst_stride = 0, tok_gate_stride = 0;
+    // decode batches on the matrix cores: scratch of the K-sliced GEMM (f32 partial tiles, per-row-group arrival counters that are
+    // zero between launches); taken from the first job of a launch, nullptr = the kernel is not used
+    float* ks_part = nullptr;
+    uint32_t* ks_cnt = nullptr;
+    size_t ks_part_cap = 0;         // floats
+    uint32_t ks_cnt_cap = 0;
 };
 uint32_t matvec_num_wg(const MatJob* jobs, int njobs, int num_cu, uint32_t* rows_per_wg);
 // dry_run: classify only (0 = a launch would honour every job's prologue / carry request, -3 = it cannot)

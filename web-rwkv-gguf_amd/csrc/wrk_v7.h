@@ -24,6 +24,7 @@ struct V7Scratch {      // Runtime<f16> + Header<f16> (v7.rs:281-383); f16 unles
     void *input, *x, *att_x, *att_v0, *rx, *wx, *kx, *vx, *ax, *gx, *r, *w, *k, *v, *a, *g, *o, *kk, *vv, *n;
     void *aux_w, *aux_a, *aux_g, *aux_v, *ffn_x, *ffn_kx, *ffn_k, *ffn_v, *ln_tmp, *head_x;
     float* head_o;      // f32 [V, num_header]
+    float* ks_part; uint32_t* ks_cnt; size_t ks_part_cap; uint32_t ks_cnt_cap;     // K-sliced GEMM scratch (2 .. 64 tokens), see MatJob
     uint32_t *cursors, *tokens, *headers, *argmax, *counter;
 };
 

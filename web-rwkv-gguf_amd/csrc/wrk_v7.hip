@@ -42,6 +42,21 @@ int32_t wrk_v7_model::ensure_scratch(uint32_t T, uint32_t NH) {
     const size_t o_headx = take(D * nh * esz), o_heado = take(V * nh * 4);
     const size_t o_cur = take((size_t)nt * 4), o_tok = take((size_t)nt * 4), o_hdr = take((size_t)nh * 4), o_arg = take((size_t)nh * 4);
     const size_t o_cnt = take(256);
+    // K-sliced GEMM (decode batches of 2 .. 64 tokens): f32 partial tiles [row group][K slice][token][64 rows] of the largest launch of a
+    // layer (at most one slice per 256-block) and one arrival counter per row group
+    size_t ks_floats = 0, ks_groups = 0, o_ksp = 0, o_ksc = 0;
+    if (nt >= 2 && act_dtype == WRK_F16) {       // (a frame sized for longer chunks still serves decode batches of up to 64)
+        const size_t ntp = nt <= 16 ? 16 : (nt <= 32 ? 32 : 64);
+        auto tiles = [](size_t m, size_t k) { return ((m + 63) / 64) * (k / 256 ? k / 256 : 1); };
+        auto groups = [](size_t m) { return (m + 63) / 64; };
+        const size_t lora = tiles(d.lora_w, D) + tiles(d.lora_a, D) + tiles(d.lora_g, D) + tiles(d.lora_v, D);
+        const size_t k1 = 3 * tiles(D, D) + lora, k5 = tiles(F, D), k6 = tiles(D, F);
+        const size_t most = k1 > k5 ? (k1 > k6 ? k1 : k6) : (k5 > k6 ? k5 : k6);
+        ks_floats = most * 64 * ntp;
+        ks_groups = 3 * groups(D) + groups(d.lora_w) + groups(d.lora_a) + groups(d.lora_g) + groups(d.lora_v) + groups(F) + 8;
+        o_ksp = take(ks_floats * 4);
+        o_ksc = take(ks_groups * 4);
+    }
     WRK_HIP(ctx, hipMalloc(&scratch, off));
     WRK_HIP(ctx, hipMemsetAsync(scratch, 0, off, ctx->stream));
     char* b = (char*)scratch;
@@ -59,6 +74,8 @@ int32_t wrk_v7_model::ensure_scratch(uint32_t T, uint32_t NH) {
     s.head_x = b + o_headx; s.head_o = (float*)(b + o_heado);
     s.cursors = (uint32_t*)(b + o_cur); s.tokens = (uint32_t*)(b + o_tok); s.headers = (uint32_t*)(b + o_hdr); s.argmax = (uint32_t*)(b + o_arg);
     s.counter = (uint32_t*)(b + o_cnt);
+    s.ks_part = ks_floats ? (float*)(b + o_ksp) : nullptr; s.ks_cnt = ks_floats ? (uint32_t*)(b + o_ksc) : nullptr;
+    s.ks_part_cap = ks_floats; s.ks_cnt_cap = (uint32_t)ks_groups;
     scratch_tokens = nt;
     scratch_headers = nh;
     // arg-max partials of the head matvec: one (value, index) per workgroup and header row

@@ -566,6 +566,7 @@ int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_
     bool single = false;        // this layer runs the 5-launch structure (prologue-fused dmv kernels)
     auto run_jobs = [&](MatJob* jobs, int n) -> int {
         if (!single && T >= gemm_min_tokens()) {
+            jobs[0].ks_part = s.ks_part; jobs[0].ks_cnt = s.ks_cnt; jobs[0].ks_part_cap = s.ks_part_cap; jobs[0].ks_cnt_cap = s.ks_cnt_cap;
             if (matmul_mfma_multi(q, jobs, n, ctx->num_cu) == 0) return 0;      // all matrices of the stage in one launch
             for (int i = 0; i < n; ++i) {
                 int rc = matmul_mfma(q, jobs[i], ctx->num_cu);
