@@ -104,6 +104,7 @@ struct LnMixParams {
     float* state_row;           // optional: shift state row, element (batch, c) at state_row[batch * state_stride + c]
     size_t state_stride;
     const uint32_t* cursors;    // batch id per token
+    uint32_t batch1;            // host-known batches: token t is batch batch1 - 1 + t (0: read the cursor)
     uint32_t no_carry;          // 1: leave the shift state alone (a later kernel of the layer still reads it: RWKV-6)
 };
 int ln_mix(hipStream_t s, const LnMixParams& P, uint32_t T);      // -1: unsupported shape (D % 8, D > 8192, nmix not in {0, 1, 2, 6})

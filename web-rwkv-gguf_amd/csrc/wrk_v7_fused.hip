@@ -47,24 +47,24 @@ __global__ void __launch_bounds__(256) ln_mix_kernel(const LnMixParams P) {
     __shared__ float red[4];
     const uint32_t t = blockIdx.x, D = P.d, nvec = D >> 3, tid = threadIdx.x;
     const size_t rowi = P.ids ? P.ids[t] : t;
-    const uint32_t batch = P.cursors ? (P.cursors[t] & 0xffu) : t;
+    const uint32_t batch = P.batch1 ? P.batch1 - 1 + t : (P.cursors ? (P.cursors[t] & 0xffu) : t);     // host-known: no scalar round trip in front of the state loads
     const f16* row = P.src + rowi * D;
-    float* st = P.state_row ? P.state_row + (size_t)batch * P.state_stride : nullptr;
+    // every load unconditional (vector index clamped, a launch without shift state reads the LN weights as a mapped dummy): the predicated
+    // form made the compiler wait vmcnt(0) in front of the statistics
+    const float* st = P.state_row ? P.state_row + (size_t)batch * P.state_stride : (const float*)P.ln_w;
     f16x8 xv[VPT], wv[VPT], bv[VPT], mv[NMIX > 0 ? NMIX : 1][VPT];
     f32x4 pv[VPT][2];
 #pragma unroll
     for (int v = 0; v < VPT; ++v) {
-        const uint32_t i = tid + 256 * v;
-        if (i < nvec) {
-            xv[v] = *(const f16x8*)(row + i * 8);
-            wv[v] = *(const f16x8*)(P.ln_w + i * 8);
-            bv[v] = *(const f16x8*)(P.ln_b + i * 8);
-            if (NMIX > 0) {
-                pv[v][0] = *(const f32x4*)(st + i * 8);
-                pv[v][1] = *(const f32x4*)(st + i * 8 + 4);
+        const uint32_t i = min(tid + 256u * v, nvec - 1);
+        xv[v] = *(const f16x8*)(row + i * 8);
+        wv[v] = *(const f16x8*)(P.ln_w + i * 8);
+        bv[v] = *(const f16x8*)(P.ln_b + i * 8);
+        if (NMIX > 0) {
+            pv[v][0] = *(const f32x4*)(st + i * 8);
+            pv[v][1] = *(const f32x4*)(st + i * 8 + 4);
 #pragma unroll
-                for (int m = 0; m < NMIX; ++m) mv[m][v] = *(const f16x8*)(P.mix[m] + i * 8);
-            }
+            for (int m = 0; m < NMIX; ++m) mv[m][v] = *(const f16x8*)(P.mix[m] + i * 8);
         }
     }
     float s = 0.0f;
@@ -106,8 +106,9 @@ __global__ void __launch_bounds__(256) ln_mix_kernel(const LnMixParams P) {
             // shift-state carry (time_mix_v7.wgsl:156-158 / channel_mix.wgsl:99-101)
             if (!P.no_carry) {
                 f32x4 n0 = {y[0], y[1], y[2], y[3]}, n1 = {y[4], y[5], y[6], y[7]};
-                *(f32x4*)(st + i * 8) = n0;
-                *(f32x4*)(st + i * 8 + 4) = n1;
+                float* sw = P.state_row + (size_t)batch * P.state_stride;
+                *(f32x4*)(sw + i * 8) = n0;
+                *(f32x4*)(sw + i * 8 + 4) = n1;
             }
         }
     }
@@ -637,7 +638,7 @@ int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_
             const wrk_buf* mx[6] = {L.x_r, L.x_w, L.x_k, L.x_v, L.x_a, L.x_g};
             void* outs[6] = {s.rx, s.wx, s.kx, s.vx, s.ax, s.gx};
             for (int i = 0; i < 6; ++i) { P.mix[i] = (const f16*)mx[i]->ptr; P.out[i] = (f16*)outs[i]; }
-            P.state_row = lst; P.state_stride = (size_t)(S + 2) * D; P.cursors = s.cursors;
+            P.state_row = lst; P.state_stride = (size_t)(S + 2) * D; P.cursors = s.cursors; P.batch1 = contiguous ? cursor0_batch + 1 : 0;
             LN(P, T);
         }
         {   // K1
@@ -699,7 +700,7 @@ int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_
             LnMixParams P{};
             P.src = (const f16*)s.x; P.ln_w = (const f16*)L.ln2_w->ptr; P.ln_b = (const f16*)L.ln2_b->ptr; P.eps = 1.0e-5f;
             P.d = D; P.nmix = 1; P.mix[0] = (const f16*)L.ffn_x_k->ptr; P.out[0] = (f16*)s.ffn_kx;
-            P.state_row = lst + (size_t)(S + 1) * D; P.state_stride = (size_t)(S + 2) * D; P.cursors = s.cursors;
+            P.state_row = lst + (size_t)(S + 1) * D; P.state_stride = (size_t)(S + 2) * D; P.cursors = s.cursors; P.batch1 = contiguous ? cursor0_batch + 1 : 0;
             LN(P, T);
         }
         {   // K5
