@@ -147,7 +147,8 @@ def test_several_sequences_decode_layer_by_layer(ctx, mode, nseq):
     run_case(ctx, "tiny", wrk.WEIGHTS_INLINE, {}, mode, [1] * nseq, 3)
 
 
-@pytest.mark.parametrize("name,nseq,kw", [("small", 9, {}), ("small", 20, {}), ("tiny", 40, {}), ("small", 12, {"mat": "Q5_K"})])
+@pytest.mark.parametrize("name,nseq,kw", [("small", 9, {}), ("small", 20, {}), ("tiny", 40, {}), ("small", 12, {"mat": "Q5_K"}),
+                                          ("small", 18, {"mat_override": {"time_mix_value": "Q6_K", "channel_mix_value": "Q6_K"}})])
 def test_decode_batches_on_the_k_sliced_gemm(ctx, name, nseq, kw, monkeypatch):
     """5 .. 32 sequences with WRK_GEMM_KS=2: every matrix of the layer goes through the K-sliced MFMA kernel (1 and 2 token tiles; K
     slices meeting through partial tiles and arrival counters for K >= 512; F16 LoRA rows in the same launch); 40 sequences stay on the

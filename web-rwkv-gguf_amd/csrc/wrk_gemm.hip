@@ -1151,9 +1151,26 @@ __device__ __forceinline__ void gemm_ks_body(const GemmParams& P, const KsJob& E
         stage[i] = *(const f16x8*)(P.x + (size_t)min(tok, P.n - 1) * P.xs + (size_t)b0 * 256 + ch * 8);
     }
     struct WBlk { u32x2 q[4]; u32x2 qh; u32x4 sm; uint32_t dd[4]; };
-    WBlk W[KIND == WRK_MAT_F16 ? 1 : BPS];
+    WBlk W[(KIND == WRK_MAT_F16 || KIND == WRK_MAT_Q6_K) ? 1 : BPS];
     f16x8 WF[KIND == WRK_MAT_F16 ? BPS : 1][8];
-    if (KIND == WRK_MAT_F16) {
+    struct W6 { u32x2 ql[4]; u32x2 qh[2]; u32x4 sc; uint32_t d[4]; };
+    W6 V6[KIND == WRK_MAT_Q6_K ? BPS : 1];
+    if (KIND == WRK_MAT_Q6_K) {
+        const uint8_t* drow[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) drow[i] = P.w + (size_t)min(m0 + 4 * g + i, P.m - 1) * P.row_bytes + (size_t)nb * 208;
+#pragma unroll
+        for (int u = 0; u < BPS; ++u) {
+            const uint32_t b = b0 + u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) V6[u].ql[j] = *(const u32x2*)(wrow + (size_t)b * 128 + j * 32 + 8 * g);       // j = 2 n128 + (kq & 1)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) V6[u].qh[h] = *(const u32x2*)(wrow + (size_t)nb * 128 + (size_t)b * 64 + h * 32 + 8 * g);
+            V6[u].sc = *(const u32x4*)(wrow + (size_t)nb * 192 + (size_t)b * 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) V6[u].d[i] = *(const uint16_t*)(drow[i] + (size_t)b * 2);
+        }
+    } else if (KIND == WRK_MAT_F16) {
         const f16* wr = (const f16*)wrow;
 #pragma unroll
         for (int u = 0; u < BPS; ++u)
@@ -1201,8 +1218,43 @@ __device__ __forceinline__ void gemm_ks_body(const GemmParams& P, const KsJob& E
             for (int sb = 0; sb < 8; ++sb)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) total[t] = mfma16(WF[u][sb], *(const f16x8*)(xt + 16 * t * ROWF + 256 * u + 32 * sb), total[t]);
+        } else if (KIND == WRK_MAT_Q6_K) {      // as gemm_body: A = (q6 - 32) * sc with sc = 2 s1 + s0 over two MFMAs, d per 256-block in f32
+            const W6& R = V6[KIND == WRK_MAT_Q6_K ? u : 0];
+            const uint32_t gsh = 8 * (g >> 1);
+            f32x4v acc[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int n128 = 0; n128 < 2; ++n128) {
+                const u32x2 qh = R.qh[n128];
+#pragma unroll
+                for (int kq = 0; kq < 4; ++kq) {
+                    const u32x2 ql = R.ql[2 * n128 + (kq & 1)];
+                    const uint32_t sh = 2 * kq;
+                    uint32_t c0, c1;
+                    if (kq < 2) { c0 = (ql.x & 0x0f0f0f0fu) | (((qh.x >> sh) & 0x03030303u) << 4); c1 = (ql.y & 0x0f0f0f0fu) | (((qh.y >> sh) & 0x03030303u) << 4); }
+                    else { c0 = ((ql.x >> 4) & 0x0f0f0f0fu) | (((qh.x >> sh) & 0x03030303u) << 4); c1 = ((ql.y >> 4) & 0x0f0f0f0fu) | (((qh.y >> sh) & 0x03030303u) << 4); }
+                    const f16x8 c = add8(mul8(codes8(c0, c1), 32768.0f), -0.0625f);
+                    const uint32_t word = R.sc[2 * n128 + (kq >> 1)];
+                    const int sc = (int)(int8_t)((word >> (16 * (kq & 1) + gsh)) & 0xffu);
+                    const int s1 = sc >> 1, s0 = sc & 1;
+                    const f16x8 a1 = mul8(c, (float)(2 * s1)), a0 = mul8(c, (float)s0);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const f16x8 bfr = *(const f16x8*)(xt + 16 * t * ROWF + 256 * u + n128 * 128 + kq * 32);
+                        acc[t] = mfma16(a1, bfr, acc[t]);
+                        acc[t] = mfma16(a0, bfr, acc[t]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float dd = (float)__builtin_bit_cast(f16, (uint16_t)R.d[i]) * 512.0f;      // * 2^9
+#pragma unroll
+                for (int t = 0; t < NT; ++t) total[t][i] = __builtin_fmaf(dd, acc[t][i], total[t][i]);
+            }
         } else {
-            const WBlk& R = W[KIND == WRK_MAT_F16 ? 0 : u];
+            const WBlk& R = W[(KIND == WRK_MAT_F16 || KIND == WRK_MAT_Q6_K) ? 0 : u];
             f32x4v acc[NT], amin[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) { acc[t] = (f32x4v){0.f, 0.f, 0.f, 0.f}; amin[t] = (f32x4v){0.f, 0.f, 0.f, 0.f}; }
@@ -1334,6 +1386,7 @@ __global__ void __launch_bounds__(256) gemm_ks_kernel(const KsBatch B) {
     switch (P.kind) {
         case WRK_MAT_Q4_K: gemm_ks_body<WRK_MAT_Q4_K, NT, BPS>(P, B.ks[ji], B.part, B.counters, lds, &sh_flag); break;
         case WRK_MAT_Q5_K: gemm_ks_body<WRK_MAT_Q5_K, NT, BPS>(P, B.ks[ji], B.part, B.counters, lds, &sh_flag); break;
+        case WRK_MAT_Q6_K: gemm_ks_body<WRK_MAT_Q6_K, NT, BPS>(P, B.ks[ji], B.part, B.counters, lds, &sh_flag); break;
         default: gemm_ks_body<WRK_MAT_F16, NT, BPS>(P, B.ks[ji], B.part, B.counters, lds, &sh_flag); break;
     }
 }
@@ -1402,7 +1455,7 @@ static int launch_ks(hipStream_t s, const MatJob* jobs, int njobs, uint32_t n) {
     }
     for (int q = 0; q < njobs; ++q) {
         const MatJob& j = jobs[q];
-        if (j.kind != WRK_MAT_Q4_K && j.kind != WRK_MAT_Q5_K && j.kind != WRK_MAT_F16) return -1;
+        if (j.kind != WRK_MAT_Q4_K && j.kind != WRK_MAT_Q5_K && j.kind != WRK_MAT_Q6_K && j.kind != WRK_MAT_F16) return -1;
         if ((j.k & 255u) || j.k < 256) return -1;
     }
     // blocks per slice: as many as still give every CU a workgroup (fewer slices = fewer partial tiles to add); the staged activation
