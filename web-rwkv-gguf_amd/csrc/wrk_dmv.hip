@@ -32,9 +32,9 @@ static dmv_fn pick_dmv_kind(int ka, bool has_f16, bool r16, int pro) {
     return nullptr;
 }
 
-dmv_fn pick_dmv_nt2(int ka, int quant2, bool has_f16, bool f16_only, uint32_t xi, int ks, int pro);
-dmv_fn pick_dmv_nt4(int ka, int quant2, bool has_f16, bool f16_only, uint32_t xi, int ks, int pro);
-dmv_fn pick_dmv_tokens(int nt, int ka, int quant2, bool has_f16, bool f16_only, uint32_t xi, int ks, int pro) {
+dmvt_fn pick_dmv_nt2(int ka, int quant2, bool has_f16, bool f16_only, uint32_t xi, int ks, int pro);
+dmvt_fn pick_dmv_nt4(int ka, int quant2, bool has_f16, bool f16_only, uint32_t xi, int ks, int pro);
+dmvt_fn pick_dmv_tokens(int nt, int ka, int quant2, bool has_f16, bool f16_only, uint32_t xi, int ks, int pro) {
     if (nt == 2) return pick_dmv_nt2(ka, quant2, has_f16, f16_only, xi, ks, pro);
     if (nt == 4) return pick_dmv_nt4(ka, quant2, has_f16, f16_only, xi, ks, pro);
     return nullptr;
@@ -45,6 +45,7 @@ int launch_dmv(hipStream_t s, const MatvecParams& P, uint32_t total_wg, int quan
     static const bool enabled = [] { const char* e = getenv("WRK_DMV"); return !(e && e[0] == '0'); }();
     if (!enabled) return -1;
     DParams D;
+    DParamsT DT;
     uint32_t bounds[7], bmask = 0, xi = 1;
     int pro = -1;
     bool small_wg = true;
@@ -82,27 +83,33 @@ int launch_dmv(hipStream_t s, const MatvecParams& P, uint32_t total_wg, int quan
         if (J.kind == WRK_MAT_F16) { nch = kpad >> 3; need = quant < 0 ? (nch + 63) / 64 : (nch + 255) / 256; bmask |= (quant < 0 ? 0u : 1u << j); }
         else { nch = (J.kind == WRK_MAT_Q8_0 || J.kind == WRK_MAT_INT8) ? (J.k >> 4) : (J.k >> 8) * 8; need = (nch + 63) / 64; }
         xi = need > xi ? need : xi;
-        DJob& d = D.jobs[j];
-        memset(&d, 0, sizeof d);
-        d.w = J.w;
-        d.x = (const f16*)J.in.p + ib;
         const size_t esz = J.out.dtype == WRK_F32 ? 4 : 2;
-        d.out = (char*)J.out.p + dense_base(J.out) * esz;
-        d.flags = J.out.dtype == WRK_F32 ? DJ_OUT32 : 0u;
-        if (J.has_res) {
-            if (J.res.dtype != WRK_F16 && J.res.dtype != WRK_F32) return -1;
-            d.res = (const char*)J.res.p + dense_base(J.res) * (J.res.dtype == WRK_F32 ? 4 : 2);
-            d.flags |= DJ_RES | (J.res.dtype == WRK_F32 ? DJ_RES32 : 0u);
+        if (J.has_res && J.res.dtype != WRK_F16 && J.res.dtype != WRK_F32) return -1;
+        auto fill = [&](auto& d) {          // the fields the one-token and the several-token job share
+            memset(&d, 0, sizeof d);
+            d.w = J.w;
+            d.x = (const f16*)J.in.p + ib;
+            d.out = (char*)J.out.p + dense_base(J.out) * esz;
+            d.flags = J.out.dtype == WRK_F32 ? DJ_OUT32 : 0u;
+            if (J.has_res) {
+                d.res = (const char*)J.res.p + dense_base(J.res) * (J.res.dtype == WRK_F32 ? 4 : 2);
+                d.flags |= DJ_RES | (J.res.dtype == WRK_F32 ? DJ_RES32 : 0u);
+            }
+            if (J.carry_dst) { d.carry_src = J.carry_src; d.carry_dst = J.carry_dst; d.flags |= DJ_CARRY; }
+            if (J.gate) { d.gate = J.gate; d.flags |= DJ_GATE; }
+            if (J.amax_val) { d.amax_val = J.amax_val; d.amax_idx = J.amax_idx; d.flags |= DJ_AMAX; }
+            if (J.pro) { d.ln_w = J.ln_w; d.ln_b = J.ln_b; d.mixw = J.mixw; d.prev = J.prev; d.ln_out = J.ln_out; d.eps = J.pro_eps; if (J.ln_out) d.flags |= DJ_PUBLISH; }
+            d.dbg = J.dbg;
+            d.k = J.k; d.m = J.m; d.row_bytes = J.row_bytes; d.rows_per_wg = J.rows_per_wg; d.wg_begin = J.wg_begin; d.act = J.act; d.kind = J.kind;
+            d.scale = J.scale;
+        };
+        if (nt == 1) fill(D.jobs[j]);
+        else {
+            DJobT& dt = DT.jobs[j];
+            fill(dt);
+            dt.ntok = ntok; dt.xs = J.in.stride[0]; dt.os = J.out.stride[0]; dt.rs = J.has_res ? J.res.stride[0] : 0;
+            dt.mix_s = J.tok_mix_stride; dt.prev_s = J.tok_prev_stride; dt.csrc_s = J.tok_carry_src_stride; dt.cdst_s = J.tok_carry_dst_stride; dt.gate_s = J.tok_gate_stride;
         }
-        if (J.carry_dst) { d.carry_src = J.carry_src; d.carry_dst = J.carry_dst; d.flags |= DJ_CARRY; }
-        if (J.gate) { d.gate = J.gate; d.flags |= DJ_GATE; }
-        if (J.amax_val) { d.amax_val = J.amax_val; d.amax_idx = J.amax_idx; d.flags |= DJ_AMAX; }
-        if (J.pro) { d.ln_w = J.ln_w; d.ln_b = J.ln_b; d.mixw = J.mixw; d.prev = J.prev; d.ln_out = J.ln_out; d.eps = J.pro_eps; if (J.ln_out) d.flags |= DJ_PUBLISH; }
-        d.dbg = J.dbg;
-        d.k = J.k; d.m = J.m; d.row_bytes = J.row_bytes; d.rows_per_wg = J.rows_per_wg; d.wg_begin = J.wg_begin; d.act = J.act; d.kind = J.kind;
-        d.scale = J.scale;
-        d.ntok = ntok; d.xs = J.in.stride[0]; d.os = J.out.stride[0]; d.rs = J.has_res ? J.res.stride[0] : 0;
-        d.mix_s = J.tok_mix_stride; d.prev_s = J.tok_prev_stride; d.csrc_s = J.tok_carry_src_stride; d.cdst_s = J.tok_carry_dst_stride; d.gate_s = J.tok_gate_stride;
         if (j > 0) bounds[j - 1] = J.wg_begin;
     }
     if (xi > 8) return -1;
@@ -127,7 +134,10 @@ int launch_dmv(hipStream_t s, const MatvecParams& P, uint32_t total_wg, int quan
             if (mixf || !small_wg || pro != 0 || amax || xi > 8) return -1;
             ks = 4; xk = xi <= 4 ? 1 : 2;
         }
-        fn = pick_dmv_tokens(nt, ka, quant2, mixf, quant < 0, xk, ks, pro);
+        const dmvt_fn ft = pick_dmv_tokens(nt, ka, quant2, mixf, quant < 0, xk, ks, pro);
+        if (!ft) return -1;
+        if (!dry) hipLaunchKernelGGL(ft, dim3(total_wg, 1), dim3(256), 0, s, bounds[0], bounds[1], bounds[2], bounds[3], bounds[4], bounds[5], bounds[6], bmask, DT);
+        return 0;
     }
     else if (quant2 >= 0) {      // (Q4_K | Q5_K) + Q6_K (+ F16): short rows, LN prologue or none
         const int k4 = quant == WRK_MAT_Q6_K ? quant2 : quant;

@@ -23,27 +23,69 @@ namespace wrk {
 // The matrix-core GEMM needs 16-token tiles and pays 7 launches per layer; up to 4 tokens this kernel keeps the 5-launch layer.
 enum { DJ_RES = 1, DJ_RES32 = 2, DJ_CARRY = 4, DJ_GATE = 8, DJ_AMAX = 16, DJ_OUT32 = 32, DJ_PUBLISH = 64 };
 
-struct DJob {
-    const uint8_t* w;
-    const f16* x;               // dense f16 inputs: token t at x + t * xs
-    void* out;                  // dense outputs: element `row` of token t at t * os + row
-    const void* res;            // DJ_RES: residual, element t * rs + row (f16; f32 with DJ_RES32)
-    const f16* carry_src;       // DJ_CARRY: carry_dst[t * cdst_s + row] = carry_src[t * csrc_s + row]
-    float* carry_dst;
-    const f16* gate;            // DJ_GATE, element t * gate_s + row
-    const f16 *ln_w, *ln_b, *mixw;      // prologue: x_in = mix(LN(x), prev, mixw); mixw of token t at t * mix_s (0: shared)
-    const float* prev;          // token t at t * prev_s
-    f16* ln_out;                // DJ_PUBLISH: the job's first workgroup stores LN(x) of token t at t * K
-    float* amax_val;            // DJ_AMAX: [workgroup][token]
-    uint32_t* amax_idx;
-    unsigned long long* dbg;
-    uint32_t k, m, row_bytes, rows_per_wg, wg_begin, act, flags, kind;
+// The job of a workgroup.  Two PLAIN structs with the same leading fields (no base class: with `struct DJobT : DJob` clang no longer
+// treated the pointer members of the by-value kernel argument as global pointers and emitted flat_load for every operand -- the
+// 2-token decode step went from 0.757 to 0.839 ms, same ISA size, same registers; found by diffing the assembly).
+// (Field order: measured.  Grouping "what every launch reads" into the leading 96 bytes made the batch-1 step 0.9 % SLOWER, 0.6213 vs
+// 0.6158 ms same-box; this order stays.)
+#define WRK_DJOB_FIELDS                                                                                                          \
+    const uint8_t* w;                                                                                                            \
+    const f16* x;          /* dense f16 inputs: token t at x + t * xs */                                                          \
+    void* out;             /* dense outputs: element `row` of token t at t * os + row */                                          \
+    const void* res;       /* DJ_RES: residual, element t * rs + row (f16; f32 with DJ_RES32) */                                  \
+    const f16* carry_src;  /* DJ_CARRY: carry_dst[t * cdst_s + row] = carry_src[t * csrc_s + row] */                              \
+    float* carry_dst;                                                                                                            \
+    const f16* gate;       /* DJ_GATE, element t * gate_s + row */                                                                \
+    const f16 *ln_w, *ln_b, *mixw; /* prologue: x_in = mix(LN(x), prev, mixw); mixw of token t at t * mix_s (0: shared) */        \
+    const float* prev;     /* token t at t * prev_s */                                                                            \
+    f16* ln_out;           /* DJ_PUBLISH: the job's first workgroup stores LN(x) of token t at t * K */                           \
+    float* amax_val;       /* DJ_AMAX: [workgroup][token] */                                                                      \
+    uint32_t* amax_idx;                                                                                                          \
+    unsigned long long* dbg;                                                                                                     \
+    uint32_t k, m, row_bytes, rows_per_wg, wg_begin, act, flags, kind;                                                           \
     float scale, eps;
+struct DJob {                   // one input vector (the batch-1 decode kernels): 160 bytes, three scalar-cache lines
+    WRK_DJOB_FIELDS
+};
+// several input vectors: the per-token strides ride behind the common part.  (They were members of DJob at first: the 196-byte struct
+// cost the ONE-token kernels 0.6 % of the decode step -- same-box A/B 0.6244 vs 0.6204 ms -- one more scalar-cache line per job read
+// at the head of every launch; so the one-token instantiations keep the 160-byte job.)
+struct DJobT {
+    WRK_DJOB_FIELDS
     uint32_t ntok, xs, os, rs, mix_s, prev_s, csrc_s, cdst_s, gate_s;
 };
 
 struct DParams {
     DJob jobs[MAX_JOBS];
+};
+struct DParamsT {
+    DJobT jobs[MAX_JOBS];
+};
+template <int NT> struct DParamsOf { typedef DParamsT type; };
+template <> struct DParamsOf<1> { typedef DParams type; };
+
+// per-token fields of a job: constants for the one-token job
+template <class JT> struct TokF {
+    static __device__ __forceinline__ uint32_t ntok(const JT&) { return 1u; }
+    static __device__ __forceinline__ uint32_t xs(const JT&) { return 0u; }
+    static __device__ __forceinline__ uint32_t os(const JT&) { return 0u; }
+    static __device__ __forceinline__ uint32_t rs(const JT&) { return 0u; }
+    static __device__ __forceinline__ uint32_t mix_s(const JT&) { return 0u; }
+    static __device__ __forceinline__ uint32_t prev_s(const JT&) { return 0u; }
+    static __device__ __forceinline__ uint32_t csrc_s(const JT&) { return 0u; }
+    static __device__ __forceinline__ uint32_t cdst_s(const JT&) { return 0u; }
+    static __device__ __forceinline__ uint32_t gate_s(const JT&) { return 0u; }
+};
+template <> struct TokF<DJobT> {
+    static __device__ __forceinline__ uint32_t ntok(const DJobT& j) { return j.ntok; }
+    static __device__ __forceinline__ uint32_t xs(const DJobT& j) { return j.xs; }
+    static __device__ __forceinline__ uint32_t os(const DJobT& j) { return j.os; }
+    static __device__ __forceinline__ uint32_t rs(const DJobT& j) { return j.rs; }
+    static __device__ __forceinline__ uint32_t mix_s(const DJobT& j) { return j.mix_s; }
+    static __device__ __forceinline__ uint32_t prev_s(const DJobT& j) { return j.prev_s; }
+    static __device__ __forceinline__ uint32_t csrc_s(const DJobT& j) { return j.csrc_s; }
+    static __device__ __forceinline__ uint32_t cdst_s(const DJobT& j) { return j.cdst_s; }
+    static __device__ __forceinline__ uint32_t gate_s(const DJobT& j) { return j.gate_s; }
 };
 
 // decode a chunk once, multiply it with the inputs of every token (arithmetic per token as dot_raw_reg)
@@ -83,8 +125,9 @@ __device__ __forceinline__ void dot_raw_tokens(const Raw& r, uint32_t c, const X
 
 // LDS: [0, 512 NT) K-split partials [NT][32 rows][4 waves] | [512 NT, 544 NT) arg-max [NT][4] values, [NT][4] indices |
 //      [544 NT, 576 NT) LN statistics [NT][8] | [576 NT, ...) the prologue's inputs [NT][kpad] f16
-template <int KIND, bool R16, int XI, int KS, int PRO, int NT>
-__device__ __forceinline__ void dmv_body(const DJob J, unsigned char* smem) {
+template <int KIND, bool R16, int XI, int KS, int PRO, int NT, class JT>
+__device__ __forceinline__ void dmv_body(const JT J, unsigned char* smem) {
+    typedef TokF<JT> TF;
     constexpr int RB = 4;
     constexpr uint32_t CSTEP = KS == 1 ? 64u : 256u;
     const uint32_t K = J.k, kpad = (K + 15u) & ~15u;
@@ -95,7 +138,7 @@ __device__ __forceinline__ void dmv_body(const DJob J, unsigned char* smem) {
     const uint32_t nch = num_chunks<KIND>(K, kpad);
     const uint32_t nrows = KS == 1 ? (r0 + wave < r1 ? (r1 - r0 - wave + 3) >> 2 : 0) : (r1 - r0);
     const uint32_t cbase = KS == 1 ? lane : lane + 64 * wave;
-    const uint32_t ntok = NT == 1 ? 1u : J.ntok;                          // 1 <= ntok <= NT; tokens beyond it are clamped and never stored
+    const uint32_t ntok = NT == 1 ? 1u : TF::ntok(J);                          // 1 <= ntok <= NT; tokens beyond it are clamped and never stored
     auto row_of = [&](uint32_t ri) { return KS == 1 ? r0 + wave + 4 * ri : r0 + ri; };
     auto tok_of = [&](uint32_t t) { return NT == 1 ? 0u : min(t, ntok - 1); };
     const uint8_t* __restrict__ W = J.w;
@@ -124,7 +167,7 @@ __device__ __forceinline__ void dmv_body(const DJob J, unsigned char* smem) {
     // epilogue operands of the (row, token) this thread will finish: KS == 1: lane rb + 4 t finishes the wave's rb-th row of a
     // batch for token t; KS == 4: thread ri + 32 t finishes row r0 + ri of token t.  Raw bits now, conversion at use.
     const uint32_t fin_row = min(KS == 1 ? row_of(lane & 3u) : r0 + (tid & 31u), r1 - 1);
-    const uint32_t fin_t = KS == 1 ? (lane >> 2) : (tid >> 5);
+    const uint32_t fin_t = NT == 1 ? 0u : (KS == 1 ? (lane >> 2) : (tid >> 5));     // (one token: everything per-token below folds away)
     const uint32_t fin_tok = tok_of(fin_t);
     const uint32_t fl = J.flags;
     uint32_t res_bits = 0, carry_bits = 0, gate_bits = 0;
@@ -146,33 +189,33 @@ __device__ __forceinline__ void dmv_body(const DJob J, unsigned char* smem) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const uint32_t tt = tok_of(t);
-                xv[t][v] = *(const f16x8*)(xin + (size_t)tt * J.xs + i * 8);
-                if (GN || t == 0) mv[GN ? t : 0][v] = *(const f16x8*)(J.mixw + (size_t)tt * J.mix_s + i * 8);
-                pv[t][v][0] = *(const f32x4*)(J.prev + (size_t)tt * J.prev_s + i * 8);
-                pv[t][v][1] = *(const f32x4*)(J.prev + (size_t)tt * J.prev_s + i * 8 + 4);
+                xv[t][v] = *(const f16x8*)(xin + (size_t)tt * TF::xs(J) + i * 8);
+                if (GN || t == 0) mv[GN ? t : 0][v] = *(const f16x8*)(J.mixw + (size_t)tt * TF::mix_s(J) + i * 8);
+                pv[t][v][0] = *(const f32x4*)(J.prev + (size_t)tt * TF::prev_s(J) + i * 8);
+                pv[t][v][1] = *(const f32x4*)(J.prev + (size_t)tt * TF::prev_s(J) + i * 8 + 4);
             }
         }
         if (!GN) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) c0h[t] = xin[(size_t)tok_of(t) * J.xs];
+            for (int t = 0; t < NT; ++t) c0h[t] = xin[(size_t)tok_of(t) * TF::xs(J)];
         }
     } else {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int ci = 0; ci < XI; ++ci) x[t][ci] = load_x<KIND>(xin + (size_t)tok_of(t) * J.xs, min(cbase + CSTEP * ci, nch - 1), true);
+            for (int ci = 0; ci < XI; ++ci) x[t][ci] = load_x<KIND>(xin + (size_t)tok_of(t) * TF::xs(J), min(cbase + CSTEP * ci, nch - 1), true);
     }
     issue(0);
     {
         const bool has_res = (fl & DJ_RES) != 0, has_carry = (fl & DJ_CARRY) != 0, has_gate = (fl & DJ_GATE) != 0;
         // absent operands read element 0 of the input vector: always mapped, never used
         const uint16_t* rp = has_res ? (const uint16_t*)J.res : (const uint16_t*)xin;
-        const uint32_t re = fin_tok * J.rs + fin_row;
+        const uint32_t re = fin_tok * TF::rs(J) + fin_row;
         const uint32_t ri = has_res ? ((fl & DJ_RES32) ? 2u * re : re) : 0u;
         if (fl & DJ_RES32) res_bits = *(const uint32_t*)(rp + ri);        // uniform branch, one load on either side
         else res_bits = rp[ri];
-        carry_bits = (has_carry ? (const uint16_t*)J.carry_src : (const uint16_t*)xin)[has_carry ? fin_tok * J.csrc_s + fin_row : 0u];
-        gate_bits = (has_gate ? (const uint16_t*)J.gate : (const uint16_t*)xin)[has_gate ? fin_tok * J.gate_s + fin_row : 0u];
+        carry_bits = (has_carry ? (const uint16_t*)J.carry_src : (const uint16_t*)xin)[has_carry ? fin_tok * TF::csrc_s(J) + fin_row : 0u];
+        gate_bits = (has_gate ? (const uint16_t*)J.gate : (const uint16_t*)xin)[has_gate ? fin_tok * TF::gate_s(J) + fin_row : 0u];
     }
 
     // ---- (2a) split-head prologue (K3): x_in = g * r16(r16(GN(y)) + tt)  with y = WKV output (f16), tt = (sum_j r_k k r) * v (f32),
@@ -286,15 +329,15 @@ __device__ __forceinline__ void dmv_body(const DJob J, unsigned char* smem) {
         const bool o32 = (fl & DJ_OUT32) != 0;
         if (fl & DJ_GATE) o = act_sigmoid(f16bits_to_f32(gbits)) * (o32 ? o : r16(o));
         if (fl & DJ_RES) o = (o32 ? o : r16(o)) + ((fl & DJ_RES32) ? __builtin_bit_cast(float, rbits) : f16bits_to_f32(rbits));
-        const size_t oo = (size_t)tok * J.os + r;
+        const size_t oo = (size_t)tok * TF::os(J) + r;
         if (o32) ((float*)J.out)[oo] = o; else ((f16*)J.out)[oo] = (f16)o;
-        if (fl & DJ_CARRY) J.carry_dst[(size_t)tok * J.cdst_s + r] = f16bits_to_f32(cbits);
+        if (fl & DJ_CARRY) J.carry_dst[(size_t)tok * TF::cdst_s(J) + r] = f16bits_to_f32(cbits);
         if (o > best_v || (o == best_v && r < best_i)) { best_v = o; best_i = r; }
     };
     auto operand_bits = [&](uint32_t r, uint32_t tok, uint32_t& rbits, uint32_t& cbits, uint32_t& gbits) {      // rows beyond the first batch
-        if (fl & DJ_RES) rbits = (fl & DJ_RES32) ? ((const uint32_t*)J.res)[(size_t)tok * J.rs + r] : (uint32_t)((const uint16_t*)J.res)[(size_t)tok * J.rs + r];
-        if (fl & DJ_CARRY) cbits = ((const uint16_t*)J.carry_src)[(size_t)tok * J.csrc_s + r];
-        if (fl & DJ_GATE) gbits = ((const uint16_t*)J.gate)[(size_t)tok * J.gate_s + r];
+        if (fl & DJ_RES) rbits = (fl & DJ_RES32) ? ((const uint32_t*)J.res)[(size_t)tok * TF::rs(J) + r] : (uint32_t)((const uint16_t*)J.res)[(size_t)tok * TF::rs(J) + r];
+        if (fl & DJ_CARRY) cbits = ((const uint16_t*)J.carry_src)[(size_t)tok * TF::csrc_s(J) + r];
+        if (fl & DJ_GATE) gbits = ((const uint16_t*)J.gate)[(size_t)tok * TF::gate_s(J) + r];
     };
     for (uint32_t ri0 = 0; ri0 < nrows; ri0 += RB) {
         if (ri0 != 0) issue(ri0);
@@ -317,13 +360,13 @@ __device__ __forceinline__ void dmv_body(const DJob J, unsigned char* smem) {
             }
         const uint32_t frb = lane & 3u;
         if (KS == 1) {
-            if (lane < (uint32_t)(RB * NT) && fin_t < ntok && ri0 + frb < nrows) {
+            if (lane < (uint32_t)(RB * NT) && (NT == 1 || fin_t < ntok) && ri0 + frb < nrows) {
                 const uint32_t r = row_of(ri0 + frb);
                 uint32_t rbits = res_bits, cbits = carry_bits, gbits = gate_bits;
                 if (ri0 != 0) operand_bits(r, fin_t, rbits, cbits, gbits);
                 finish(r, fin_t, mine_v, rbits, cbits, gbits);
             }
-        } else if (lane < (uint32_t)(RB * NT) && ri0 + frb < nrows) part[(((lane >> 2) * 32u) + ri0 + frb) * 4 + wave] = mine_v;
+        } else if (lane < (uint32_t)(RB * NT) && ri0 + frb < nrows) part[(((NT == 1 ? 0u : lane >> 2) * 32u) + ri0 + frb) * 4 + wave] = mine_v;
     }
     if (KS == 4) {
         __syncthreads();
@@ -362,11 +405,11 @@ constexpr unsigned dmv_smem_bytes() { return 576u * NT + (PRO > 0 ? (unsigned)((
 // launch, so the job lookup costs no memory access and the job's parameters are the kernel's first (and only) scalar round trip
 template <int KA, int KB, bool R16, int XI, int KS, int PRO, int NT>
 __global__ void __launch_bounds__(256) dmv_kernel(uint32_t b1, uint32_t b2, uint32_t b3, uint32_t b4, uint32_t b5, uint32_t b6, uint32_t b7,
-                                                  uint32_t kind_b_mask, const DParams P) {
+                                                  uint32_t kind_b_mask, const typename DParamsOf<NT>::type P) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[dmv_smem_bytes<PRO, NT>()];
     const uint32_t b = blockIdx.x;
     const uint32_t ji = (b >= b1) + (b >= b2) + (b >= b3) + (b >= b4) + (b >= b5) + (b >= b6) + (b >= b7);
-    const DJob J = P.jobs[ji];
+    const auto J = P.jobs[ji];
     if (KA == KB || !((kind_b_mask >> ji) & 1u)) dmv_body<KA, (KA != WRK_MAT_F16) && R16, XI, KS, PRO, NT>(J, smem);
     else dmv_body<KB, (KB != WRK_MAT_F16) && R16, (KB == WRK_MAT_F16 ? 4 * XI : XI), 1, PRO, NT>(J, smem);
 }
@@ -375,19 +418,20 @@ __global__ void __launch_bounds__(256) dmv_kernel(uint32_t b1, uint32_t b2, uint
 // value is Q6_K in about half of the layers (KS == 1; the job's own kind field selects the body)
 template <int KA, bool R16, int XI, int PRO, int NT>
 __global__ void __launch_bounds__(256) dmv3_kernel(uint32_t b1, uint32_t b2, uint32_t b3, uint32_t b4, uint32_t b5, uint32_t b6, uint32_t b7,
-                                                   uint32_t, const DParams P) {
+                                                   uint32_t, const typename DParamsOf<NT>::type P) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[dmv_smem_bytes<PRO, NT>()];
     const uint32_t b = blockIdx.x;
     const uint32_t ji = (b >= b1) + (b >= b2) + (b >= b3) + (b >= b4) + (b >= b5) + (b >= b6) + (b >= b7);
-    const DJob J = P.jobs[ji];
+    const auto J = P.jobs[ji];
     if (J.kind == (uint32_t)KA) dmv_body<KA, R16, XI, 1, PRO, NT>(J, smem);
     else if (J.kind == WRK_MAT_Q6_K) dmv_body<WRK_MAT_Q6_K, R16, XI, 1, PRO, NT>(J, smem);
     else dmv_body<WRK_MAT_F16, false, 4 * XI, 1, PRO, NT>(J, smem);
 }
 
 typedef void (*dmv_fn)(uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const DParams);
+typedef void (*dmvt_fn)(uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const DParamsT);
 
 // wrk_dmvt.hip: the kernel for NT = 2 or 4 tokens (nullptr: combination not instantiated)
-dmv_fn pick_dmv_tokens(int nt, int ka, int quant2, bool has_f16, bool f16_only, uint32_t xi, int ks, int pro);
+dmvt_fn pick_dmv_tokens(int nt, int ka, int quant2, bool has_f16, bool f16_only, uint32_t xi, int ks, int pro);
 
 }  // namespace wrk

@@ -9,20 +9,20 @@ namespace wrk {
 #define NTK DMVT_NT
 
 template <int KA, int KB, int XI>
-static dmv_fn pick_pro(int pro) {
+static dmvt_fn pick_pro(int pro) {
     constexpr int P1 = XI == 1 ? 1 : 2, P3 = XI == 1 ? 3 : 4;
-    if (pro == 0) return (dmv_fn)dmv_kernel<KA, KB, false, XI, 1, 0, NTK>;
-    if (pro == P1) return (dmv_fn)dmv_kernel<KA, KB, false, XI, 1, P1, NTK>;
-    if (pro == P3 && KA == KB) return (dmv_fn)dmv_kernel<KA, KA, false, XI, 1, P3, NTK>;
+    if (pro == 0) return (dmvt_fn)dmv_kernel<KA, KB, false, XI, 1, 0, NTK>;
+    if (pro == P1) return (dmvt_fn)dmv_kernel<KA, KB, false, XI, 1, P1, NTK>;
+    if (pro == P3 && KA == KB) return (dmvt_fn)dmv_kernel<KA, KA, false, XI, 1, P3, NTK>;
     return nullptr;
 }
 
 template <int KA>
-static dmv_fn pick_kind(bool has_f16, uint32_t xi, int ks, int pro) {
+static dmvt_fn pick_kind(bool has_f16, uint32_t xi, int ks, int pro) {
     if (ks == 4) {
         if (has_f16 || pro != 0) return nullptr;
-        if (xi == 1) return (dmv_fn)dmv_kernel<KA, KA, false, 1, 4, 0, NTK>;
-        if (xi == 2 && NTK < 8) return (dmv_fn)dmv_kernel<KA, KA, false, (NTK < 8 ? 2 : 1), 4, 0, NTK>;
+        if (xi == 1) return (dmvt_fn)dmv_kernel<KA, KA, false, 1, 4, 0, NTK>;
+        if (xi == 2 && NTK < 8) return (dmvt_fn)dmv_kernel<KA, KA, false, (NTK < 8 ? 2 : 1), 4, 0, NTK>;
         return nullptr;
     }
     if (xi == 1) return has_f16 ? pick_pro<KA, WRK_MAT_F16, 1>(pro) : pick_pro<KA, KA, 1>(pro);
@@ -32,19 +32,19 @@ static dmv_fn pick_kind(bool has_f16, uint32_t xi, int ks, int pro) {
 
 #define CAT2(a, b) a##b
 #define CAT(a, b) CAT2(a, b)
-dmv_fn CAT(pick_dmv_nt, DMVT_NT)(int ka, int quant2, bool has_f16, bool f16_only, uint32_t xi, int ks, int pro) {
+dmvt_fn CAT(pick_dmv_nt, DMVT_NT)(int ka, int quant2, bool has_f16, bool f16_only, uint32_t xi, int ks, int pro) {
     if (quant2 >= 0) {
         const int k4 = ka == WRK_MAT_Q6_K ? quant2 : ka;
         if ((ka != WRK_MAT_Q6_K && quant2 != WRK_MAT_Q6_K) || xi != 1 || ks != 1 || pro > 1) return nullptr;
-        if (k4 == WRK_MAT_Q4_K) return pro == 1 ? (dmv_fn)dmv3_kernel<WRK_MAT_Q4_K, false, 1, 1, NTK> : (dmv_fn)dmv3_kernel<WRK_MAT_Q4_K, false, 1, 0, NTK>;
-        if (k4 == WRK_MAT_Q5_K) return pro == 1 ? (dmv_fn)dmv3_kernel<WRK_MAT_Q5_K, false, 1, 1, NTK> : (dmv_fn)dmv3_kernel<WRK_MAT_Q5_K, false, 1, 0, NTK>;
+        if (k4 == WRK_MAT_Q4_K) return pro == 1 ? (dmvt_fn)dmv3_kernel<WRK_MAT_Q4_K, false, 1, 1, NTK> : (dmvt_fn)dmv3_kernel<WRK_MAT_Q4_K, false, 1, 0, NTK>;
+        if (k4 == WRK_MAT_Q5_K) return pro == 1 ? (dmvt_fn)dmv3_kernel<WRK_MAT_Q5_K, false, 1, 1, NTK> : (dmvt_fn)dmv3_kernel<WRK_MAT_Q5_K, false, 1, 0, NTK>;
         return nullptr;
     }
     if (f16_only) {     // F16 rows alone (a head kept in f16, LoRA rows): no prologue
         if (ks != 1 || pro != 0) return nullptr;
-        if (xi == 1) return (dmv_fn)dmv_kernel<WRK_MAT_F16, WRK_MAT_F16, false, 1, 1, 0, NTK>;
-        if (xi == 2) return (dmv_fn)dmv_kernel<WRK_MAT_F16, WRK_MAT_F16, false, 2, 1, 0, NTK>;
-        if (xi <= 4) return (dmv_fn)dmv_kernel<WRK_MAT_F16, WRK_MAT_F16, false, 4, 1, 0, NTK>;
+        if (xi == 1) return (dmvt_fn)dmv_kernel<WRK_MAT_F16, WRK_MAT_F16, false, 1, 1, 0, NTK>;
+        if (xi == 2) return (dmvt_fn)dmv_kernel<WRK_MAT_F16, WRK_MAT_F16, false, 2, 1, 0, NTK>;
+        if (xi <= 4) return (dmvt_fn)dmv_kernel<WRK_MAT_F16, WRK_MAT_F16, false, 4, 1, 0, NTK>;
         return nullptr;
     }
     switch (ka) {
