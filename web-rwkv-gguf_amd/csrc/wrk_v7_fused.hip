@@ -160,8 +160,11 @@ template <int MAXCH>
 __device__ __forceinline__ void lora_load(LoraRegs<MAXCH>& r, const f16* __restrict__ wrow, const f16* __restrict__ aux, uint32_t rank, uint32_t part) {
 #pragma unroll
     for (int n = 0; n < MAXCH; ++n) {
-        const uint32_t c = part * 8 + 32 * n;
-        if (c < rank) { r.w[n] = *(const f16x8*)(wrow + c); r.x[n] = *(const f16x8*)(aux + c); }
+        // unconditional (column clamped; lora_dot masks the chunks beyond the rank): predicated loads make the compiler lose count of
+        // what is in flight and wait vmcnt(0) between dependent groups
+        const uint32_t c = min(part * 8 + 32 * n, rank - 8);
+        r.w[n] = *(const f16x8*)(wrow + c);
+        r.x[n] = *(const f16x8*)(aux + c);
     }
 }
 
@@ -206,11 +209,11 @@ __global__ void __launch_bounds__(256) head_kernel(const HeadParams P) {
     const float w0 = (float)P.w0[ch], a0 = (float)P.a0[ch], kkw = (float)P.k_k[ch], kaw = (float)P.k_a[ch];
     const float kraw = (float)P.k[(size_t)t * D + ch], rraw = (float)P.r[(size_t)t * D + ch];
     float v = (float)P.v[(size_t)t * D + ch];
-    float v0w = 0.0f, vfirst = 0.0f;
-    if (!P.layer0) { v0w = (float)P.v0[ch]; vfirst = (float)P.v_first[(size_t)t * D + ch]; }
+    // unconditional (as in head_split_kernel): layer 0 reads w0 / its own v_first slot as dummies, no shift source reads w0
+    const f16 v0h = (P.layer0 ? P.w0 : P.v0)[ch], vfh = P.v_first[(size_t)t * D + ch];
+    const float v0w = P.layer0 ? 0.0f : (float)v0h, vfirst = P.layer0 ? 0.0f : (float)vfh;
     const float gnw = (float)P.gn_w[c0 + i], gnb = (float)P.gn_b[c0 + i], rkw = (float)P.r_k[c0 + i];
-    float shift = 0.0f;
-    if (P.shift_src && g4 == 1) shift = (float)P.shift_src[(size_t)t * D + c0 + i];
+    const float shift = (float)(P.shift_src ? P.shift_src + (size_t)t * D : P.w0)[c0 + i];
 
     // (2) state of this thread's column slice S[16*g4 .. +15][i]: needs the batch id; requested last, consumed last
     const uint32_t batch = P.batch1 ? P.batch1 - 1 + t : (P.cursors[t] & 0xffu);
@@ -340,9 +343,12 @@ __global__ void __launch_bounds__(256) head_split_kernel(const HeadParams P, flo
     const float w0 = (float)P.w0[ch], a0 = (float)P.a0[ch], kkw = (float)P.k_k[ch], kaw = (float)P.k_a[ch], rkw = (float)P.r_k[ch];
     const float kraw = (float)P.k[(size_t)t * D + ch], rraw = (float)P.r[(size_t)t * D + ch];
     float v = (float)P.v[(size_t)t * D + chq];
-    const float v0w = P.layer0 ? 0.0f : (float)P.v0[chq], vfirst = P.layer0 ? 0.0f : (float)P.v_first[(size_t)t * D + chq];
-    float shift = 0.0f;
-    if (P.shift_src && tid < C) shift = (float)P.shift_src[(size_t)t * D + cq + tid];
+    // unconditional loads (round 2: each of these was `if (...) load; s_waitcnt vmcnt(0)` -- two serial memory round trips behind the LoRA
+    // burst): layer 0 reads w0 / its own v_first slot as mapped dummies, a launch without shift source reads w0
+    const f16 v0h = (P.layer0 ? P.w0 : P.v0)[chq], vfh = P.v_first[(size_t)t * D + chq];
+    const f16 shh = (P.shift_src ? P.shift_src + (size_t)t * D + cq : P.w0 + cq)[min(tid, (uint32_t)C - 1)];
+    const float v0w = P.layer0 ? 0.0f : (float)v0h, vfirst = P.layer0 ? 0.0f : (float)vfh;
+    const float shift = (float)shh;
 
     // (2) the state slice: thread (wave, lane = j) holds S[j][cq + 4*wave .. +3]; requested last, consumed last
     const uint32_t batch = P.batch1 ? P.batch1 - 1 + t : (P.cursors[t] & 0xffu);
