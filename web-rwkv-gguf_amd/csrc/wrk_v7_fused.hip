@@ -682,7 +682,7 @@ int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_
             P.v_first = (f16*)s.att_v0; P.out = (f16*)s.att_x;
             P.state = lst; P.cursors = s.cursors; P.gn_eps = 64.0e-5f; P.l2_eps = 1.0e-12f;
             P.shift_src = single ? (const f16*)s.ln_tmp : nullptr;     // fused K0: the state carry happens here
-            P.batch1 = single ? batch0 + 1 : 0;                         // token t is batch batch0 + t
+            P.batch1 = (single || contiguous) ? cursor0_batch + 1 : 0;  // host-known batches: token t is batch cursor0_batch + t (no cursor load in front of the state loads)
             P.dbg = li == TIMED_LAYER ? wrk::timing_slot(ctx, "K2 head: LoRA-2 + WKV7 + group norm") : nullptr;
             if (split_head) {
                 if (d.lora_g <= 256) head_split_kernel<2><<<dim3(H * 4, T), 256, 0, q>>>(P, (float*)s.n, (f16*)s.g, H);
