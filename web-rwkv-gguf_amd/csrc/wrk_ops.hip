@@ -404,9 +404,12 @@ __global__ void __launch_bounds__(256) time_mix_v7_fast_kernel(const uint32_t* _
 
     // token-shift carry: state row 0 <- att_x of the sequence's last token (read before it is overwritten)
     if (part == 0) dt_store(st, dt_index(st, ch, 0, cur.batch), dt_load(x, dt_index(x, i, head, tend - 1)));
+    // the state is f32 here (host-checked): plain loads, all sixteen in flight at once (dt_load branches on the element type, and the
+    // compiler then waited vmcnt(0) after every one of them: sixteen serial round trips at the head of every chunk)
     float Sreg[16];
+    float* sbase = (float*)st.p;
 #pragma unroll
-    for (int jj = 0; jj < 16; ++jj) Sreg[jj] = dt_load(st, dt_index(st, ch, 1 + part * 16 + jj, cur.batch));
+    for (int jj = 0; jj < 16; ++jj) Sreg[jj] = sbase[dt_index(st, ch, 1 + part * 16 + jj, cur.batch)];
 
     struct Tok { f16x8 r[2], k[2], a[2], kk[2]; f16 v; f16 wraw; };
     // per-token pointers advance by constant strides (dense f16 views): no index arithmetic inside the loop
@@ -425,51 +428,67 @@ __global__ void __launch_bounds__(256) time_mix_v7_fast_kernel(const uint32_t* _
     auto load_tok = [&](Tok& T, bool adv) {       // advances the pointers (unless at the end), then loads the token they stand on
         const size_t rs = adv ? rstep : 0, ns = adv ? nstep : 0, ws = adv ? wstep : 0;
         rp += rs; kp += ns; ap += ns; qp += ns; vp += ns; wp += ws;
+        T.wraw = *wp;                               // first of its group: the decay of token t + 1 is needed one step before the rest
         T.r[0] = *(const f16x8*)rp; T.r[1] = *(const f16x8*)(rp + 8);
         T.k[0] = *(const f16x8*)kp; T.k[1] = *(const f16x8*)(kp + 8);
         T.a[0] = *(const f16x8*)ap; T.a[1] = *(const f16x8*)(ap + 8);
         T.kk[0] = *(const f16x8*)qp; T.kk[1] = *(const f16x8*)(qp + 8);
         T.v = *vp;
-        T.wraw = *wp;
     };
-    Tok curT, nxtT;
-    load_tok(curT, false);
-    if (tid < S) sh_w[cur.token & 1u][tid] = __expf(-0.606531f * act_sigmoid((float)curT.wraw));
-    for (uint32_t t = cur.token; t < tend; ++t) {
-        const bool more = t + 1 < tend;
-        load_tok(nxtT, more);
-        __syncthreads();                                        // w~ of token t is in sh_w[t & 1]
-        const float* wt = sh_w[t & 1u] + part * 16;
-        float wv[16];
+    // Tokens are requested NPF - 1 steps ahead: a ring of NPF register sets, the loop unrolled by NPF so every index is static, and NO
+    // control flow around the steps (steps beyond the chunk run on the clamped last token and are masked: the first attempt had a `break`
+    // in the unrolled body and the compiler fell back to vmcnt(0)).  With ONE token of lookahead every step ended in `s_waitcnt vmcnt(0)`
+    // for the decay of the next token -- the youngest load -- i.e. a full memory round trip per token: 2.4 us x 128 tokens per layer in
+    // the 32 x 128-token prefill (found in the ISA, round 2).
+    // (measured, 32 x 128-token prefill, tokens/s: ring of 3 101.6 k | ring of 2 99.6 k | ring of 4 100.7 k | register caps that restore four
+    // workgroups per CU spill: 100.3 k / 87.1 k; one token of lookahead, before: 97.5 k)
+    constexpr int NPF = 3;
+    Tok T[NPF];
+    uint32_t lpos = cur.token;                      // token the pointers stand on
+    load_tok(T[0], false);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { const f32x4 v4 = *(const f32x4*)(wt + 4 * q); wv[4 * q] = v4[0]; wv[4 * q + 1] = v4[1]; wv[4 * q + 2] = v4[2]; wv[4 * q + 3] = v4[3]; }
-        // four independent FMA chains per reduction (a wave runs alone on its SIMD: latency, not issue, is the cost)
-        float kkf[16], s4[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int u = 1; u < NPF; ++u) { const bool adv = lpos + 1 < tend; load_tok(T[u], adv); lpos += adv ? 1u : 0u; }
+    if (tid < S) sh_w[cur.token & 1u][tid] = __expf(-0.606531f * act_sigmoid((float)T[0].wraw));
+    for (uint32_t tb = cur.token; tb < tend; tb += NPF) {
 #pragma unroll
-        for (int jj = 0; jj < 16; ++jj) { kkf[jj] = (float)curT.kk[jj >> 3][jj & 7]; s4[jj & 3] = __builtin_fmaf(Sreg[jj], -kkf[jj], s4[jj & 3]); }   // a~ = -kk
-        float sa = (s4[0] + s4[1]) + (s4[2] + s4[3]);
-        sa = (sa + __shfl_xor(sa, 1, WAVE));
-        sa = (sa + __shfl_xor(sa, 2, WAVE));
-        const float vv = (float)curT.v;
-        float y4[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < NPF; ++u) {
+            const uint32_t t = tb + u;
+            const bool valid = t < tend;                            // uniform; a masked step changes nothing
+            const Tok& curT = T[u];
+            __syncthreads();                                        // w~ of token t is in sh_w[t & 1]
+            const float* wt = sh_w[t & 1u] + part * 16;
+            float wv[16];
 #pragma unroll
-        for (int jj = 0; jj < 16; ++jj) {
-            const float kj = (float)curT.k[jj >> 3][jj & 7], aj = (float)curT.a[jj >> 3][jj & 7];
-            const float sn = Sreg[jj] * wv[jj] + kj * vv + sa * (kkf[jj] * aj);                                  // b~ = kk * a
-            Sreg[jj] = sn;
-            y4[jj & 3] = __builtin_fmaf((float)curT.r[jj >> 3][jj & 7], sn, y4[jj & 3]);
+            for (int q = 0; q < 4; ++q) { const f32x4 v4 = *(const f32x4*)(wt + 4 * q); wv[4 * q] = v4[0]; wv[4 * q + 1] = v4[1]; wv[4 * q + 2] = v4[2]; wv[4 * q + 3] = v4[3]; }
+            // four independent FMA chains per reduction (a wave runs alone on its SIMD: latency, not issue, is the cost)
+            float kkf[16], s4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) { kkf[jj] = (float)curT.kk[jj >> 3][jj & 7]; s4[jj & 3] = __builtin_fmaf(Sreg[jj], -kkf[jj], s4[jj & 3]); }   // a~ = -kk
+            float sa = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+            sa = (sa + __shfl_xor(sa, 1, WAVE));
+            sa = (sa + __shfl_xor(sa, 2, WAVE));
+            const float vv = (float)curT.v;
+            float y4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) {
+                const float kj = (float)curT.k[jj >> 3][jj & 7], aj = (float)curT.a[jj >> 3][jj & 7];
+                const float sn = Sreg[jj] * wv[jj] + kj * vv + sa * (kkf[jj] * aj);                                  // b~ = kk * a
+                Sreg[jj] = valid ? sn : Sreg[jj];
+                y4[jj & 3] = __builtin_fmaf((float)curT.r[jj >> 3][jj & 7], sn, y4[jj & 3]);
+            }
+            float y = (y4[0] + y4[1]) + (y4[2] + y4[3]);
+            y = (y + __shfl_xor(y, 1, WAVE));
+            y = (y + __shfl_xor(y, 2, WAVE));
+            if (valid && part == 0) *xp = (f16)y;
+            xp += valid ? xstep : 0;
+            // w~ of the next token (the last token's again at the end of the chunk)
+            if (tid < S) sh_w[(t + 1) & 1u][tid] = __expf(-0.606531f * act_sigmoid((float)T[(u + 1) % NPF].wraw));
+            // this register set is free: request token t + NPF (the last token again once the chunk ends; discarded)
+            { const bool adv = lpos + 1 < tend; load_tok(T[u], adv); lpos += adv ? 1u : 0u; }
         }
-        float y = (y4[0] + y4[1]) + (y4[2] + y4[3]);
-        y = (y + __shfl_xor(y, 1, WAVE));
-        y = (y + __shfl_xor(y, 2, WAVE));
-        if (part == 0) *xp = (f16)y;
-        xp += xstep;
-        // w~ of the next token (harmless recomputation of the last token's at the end)
-        if (tid < S) sh_w[(t + 1) & 1u][tid] = __expf(-0.606531f * act_sigmoid((float)nxtT.wraw));
-        curT = nxtT;
     }
 #pragma unroll
-    for (int jj = 0; jj < 16; ++jj) dt_store(st, dt_index(st, ch, 1 + part * 16 + jj, cur.batch), Sreg[jj]);
+    for (int jj = 0; jj < 16; ++jj) sbase[dt_index(st, ch, 1 + part * 16 + jj, cur.batch)] = Sreg[jj];
 }
 
 static bool dense_f16_heads(const DTensor& d) {
