@@ -523,18 +523,21 @@ struct PreWkvParams {
 __global__ void __launch_bounds__(64) pre_wkv_v7_kernel(const PreWkvParams P) {
     const uint32_t head = blockIdx.x, t = blockIdx.y, c = head * 64 + threadIdx.x;
     const size_t i = (size_t)t * P.D + c, plane = (size_t)P.T * P.D;
-    const f16 wn = to_h((float)P.w0[c] + (float)P.w[i]);
-    const f16 an = to_h(act_sigmoid((float)P.a0[c] + (float)P.a[i]));
-    const f16 k0 = P.k[i];
-    const f16 kk0 = to_h((float)P.k_k[c] * (float)k0);
+    // every operand requested up front (round 2: the loads were interleaved with the rounding barriers of to_h and each group ended in
+    // vmcnt(0): seven serial round trips per wave); layer 0 reads its own v0 slot / vv as dummies
+    const f16 w0c = P.w0[c], wi = P.w[i], a0c = P.a0[c], ai = P.a[i], k0 = P.k[i], kkc = P.k_k[c], kac = P.k_a[c], vi = P.v[i];
+    const f16 v0pc = (P.first_layer ? P.k_a : P.v0p)[c], vvi = (P.first_layer ? P.v : P.vv)[i], v0i = P.v0[i];
+    const f16 wn = to_h((float)w0c + (float)wi);
+    const f16 an = to_h(act_sigmoid((float)a0c + (float)ai));
+    const f16 kk0 = to_h((float)kkc * (float)k0);
     const float ss = wave_sum((float)kk0 * (float)kk0);
     const f16 kk1 = to_h((float)kk0 * (1.0f / sqrtf(ss + P.l2_eps)));
-    const f16 kn = to_h((float)k0 * (1.0f + ((float)an - 1.0f) * (float)P.k_a[c]));
-    f16 vn = P.v[i];
+    const f16 kn = to_h((float)k0 * (1.0f + ((float)an - 1.0f) * (float)kac));
+    f16 vn = vi;
     if (P.first_layer) P.v0[i] = vn;
     else {
-        const f16 f = to_h(act_sigmoid((float)P.v0p[c] + (float)P.vv[i]));
-        vn = to_h(wgsl_mix((float)vn, (float)P.v0[i], (float)f));
+        const f16 f = to_h(act_sigmoid((float)v0pc + (float)vvi));
+        vn = to_h(wgsl_mix((float)vn, (float)v0i, (float)f));
     }
     P.w[i] = wn;
     P.n[i] = kn;
@@ -560,15 +563,16 @@ struct PostWkvParams {
 __global__ void __launch_bounds__(64) post_wkv_v7_kernel(const PostWkvParams P) {
     const uint32_t head = blockIdx.x, t = blockIdx.y, c = head * 64 + threadIdx.x;
     const size_t i = (size_t)t * P.D + c, plane = (size_t)P.T * P.D;
-    const float x0 = (float)P.x[i];
+    const f16 xi = P.x[i], gw = P.gn_w[c], gb = P.gn_b[c], rk = P.r_k[c], n0 = P.n[i], ri = P.r[i], n1 = P.n[plane + i], gi = P.g[i];    // all up front
+    const float x0 = (float)xi;
     const float mean = wave_sum(x0) / 64.0f;
     const float dlt = x0 - mean;
     const float var = wave_sum(dlt * dlt) / 64.0f + P.gn_eps;
     const float dev = 1.0f / sqrtf(var);
-    const f16 y = to_h(__builtin_fmaf((x0 - mean) * dev, (float)P.gn_w[c], (float)P.gn_b[c]));
-    const float xx = wave_sum((float)P.r_k[c] * (float)P.n[i] * (float)P.r[i]);
-    const f16 y2 = to_h((float)y + xx * (float)P.n[plane + i]);
-    P.x[i] = to_h((float)P.g[i] * (float)y2);
+    const f16 y = to_h(__builtin_fmaf((x0 - mean) * dev, (float)gw, (float)gb));
+    const float xx = wave_sum((float)rk * (float)n0 * (float)ri);
+    const f16 y2 = to_h((float)y + xx * (float)n1);
+    P.x[i] = to_h((float)gi * (float)y2);
 }
 void post_wkv_v7(hipStream_t s, void* x, const void* r, const void* g, const void* n, const void* gn_w, const void* gn_b, const void* r_k,
                  uint32_t D, uint32_t T, float gn_eps) {
