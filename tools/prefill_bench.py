@@ -52,7 +52,7 @@ def main():
         if rep and (best is None or dt < best):
             best = dt
     total = a.prompt * a.batch
-    print(json.dumps({"workload": f"{'RWKV-6' if a.model in bench.CONFIGS_V6 else 'RWKV-7'} {a.model} {'Q5_K_M' if a.model in bench.CONFIGS_V6 else ('Q4_K_M mix' if a.mixed else 'Q4_K')} prefill, {a.batch} x {a.prompt} tokens, chunk {a.chunk}", "chunks": n,
+    print(json.dumps({"workload": f"{'RWKV-6' if a.model in bench.CONFIGS_V6 else 'RWKV-7'} {a.model} {('Q8_0' if a.model.startswith('v6-14B') else 'Q5_K_M') if a.model in bench.CONFIGS_V6 else ('Q4_K_M mix' if a.mixed else 'Q4_K')} prefill, {a.batch} x {a.prompt} tokens, chunk {a.chunk}", "chunks": n,
                       "tokens_per_s": round(total / best, 1), "ms": round(best * 1e3, 3),
                       "matrix_TFLOPs": round(total * flop_tok / best / 1e12, 2), "mfma_peak_TFLOPs_f16_dense": 2500.0}))
 
