@@ -1053,6 +1053,80 @@ __device__ __forceinline__ void gemm_tile2_body_q8(const GemmParams& P, f16* __r
     }
 }
 
+// F16 rows on the same tile (LoRA down-projections in prefill: K = D; any F16 matrix with K % 128 == 0): the A fragments come straight
+// from memory, one half block (four 32-k steps) ahead; accumulation over the whole K in the matrix core.
+template <int TT>
+__device__ __forceinline__ void gemm_tile2_body_f16(const GemmParams& P, f16* __restrict__ lds) {
+    constexpr int TOK = 16 * TT, NST = TOK * 16 / 256;
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const uint32_t r = lane & 15, g = lane >> 4;
+    const uint32_t m0 = (blockIdx.x - P.wg_begin) * TILE_ROWS + wave * 16;
+    const uint32_t n0 = blockIdx.y * TOK;
+    const uint32_t K = P.k, nhalf = K >> 7;
+    const f16* wrow = (const f16*)(P.w + (size_t)min(m0 + r, P.m - 1) * P.row_bytes) + 8 * g;
+    const f16* xsrc[NST];
+#pragma unroll
+    for (int q = 0; q < NST; ++q) xsrc[q] = P.x + (size_t)min(n0 + (tid >> 4) + 16 * q, P.n - 1) * P.xs + (tid & 15u) * 8;
+    f16x8 stage[NST];
+    auto fetch_x = [&](uint32_t h) {
+        const uint32_t hc = min(h, nhalf - 1);
+#pragma unroll
+        for (int q = 0; q < NST; ++q) stage[q] = *(const f16x8*)(xsrc[q] + (size_t)hc * T2_KH);
+    };
+    auto store_x = [&](uint32_t buf) {
+        f16* base = lds + (size_t)buf * TOK * T2_ROW;
+#pragma unroll
+        for (int q = 0; q < NST; ++q) *(f16x8*)(base + ((tid >> 4) + 16 * q) * T2_ROW + (tid & 15u) * 8) = stage[q];
+    };
+    struct WF { f16x8 a[4]; };
+    auto load_w = [&](WF& R, uint32_t h) {
+        const uint32_t hc = min(h, nhalf - 1);
+#pragma unroll
+        for (int st = 0; st < 4; ++st) R.a[st] = *(const f16x8*)(wrow + (size_t)hc * 128 + st * 32);
+    };
+    f32x4v total[TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) total[t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+    WF W0, W1;
+    fetch_x(0);
+    load_w(W0, 0);
+    store_x(0);
+    __syncthreads();
+    auto half = [&](uint32_t h, uint32_t buf, const WF& R, WF& Rn) {
+        fetch_x(h + 1);
+        load_w(Rn, h + 1);
+        const f16* xt = lds + (size_t)buf * TOK * T2_ROW + r * T2_ROW + 8 * g;
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+            for (int t = 0; t < TT; ++t) total[t] = mfma16(R.a[st], *(const f16x8*)(xt + (size_t)t * 16 * T2_ROW + st * 32), total[t]);
+        store_x(buf ^ 1u);
+        __syncthreads();
+    };
+    for (uint32_t h = 0; h < nhalf; h += 2) {       // uniform over the workgroup
+        half(h, 0u, W0, W1);
+        if (h + 1 >= nhalf) break;
+        half(h + 1, 1u, W1, W0);
+    }
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        const uint32_t tok = n0 + 16 * t + r;
+        if (tok >= P.n || m0 + 4 * g >= P.m) continue;
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = act_apply(P.act, total[t][i] * P.scale);
+        const size_t oo = (size_t)tok * P.os + m0 + 4 * g;
+        if (P.has_res) {
+            const size_t ro = (size_t)tok * P.rs + m0 + 4 * g;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = (P.out32 ? o[i] : r16(o[i])) + (P.res32 ? ((const float*)P.res_p)[ro + i] : (float)((const f16*)P.res_p)[ro + i]);
+        }
+        if (P.out32) *(f32x4v*)((float*)P.out_p + oo) = (f32x4v){o[0], o[1], o[2], o[3]};
+        else { typedef _Float16 f16x4 __attribute__((ext_vector_type(4))); *(f16x4*)((f16*)P.out_p + oo) = (f16x4){(f16)o[0], (f16)o[1], (f16)o[2], (f16)o[3]}; }
+    }
+}
+
 template <int TT>
 __global__ void __launch_bounds__(256) gemm_tile2_kernel(const GemmBatch B) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tile2_smem[];
@@ -1063,7 +1137,8 @@ __global__ void __launch_bounds__(256) gemm_tile2_kernel(const GemmBatch B) {
     const GemmParams& P = B.jobs[ji];
     if (P.kind == WRK_MAT_Q4_K) gemm_tile2_body<WRK_MAT_Q4_K, TT>(P, (f16*)tile2_smem);
     else if (P.kind == WRK_MAT_Q5_K) gemm_tile2_body<WRK_MAT_Q5_K, TT>(P, (f16*)tile2_smem);
-    else gemm_tile2_body_q8<TT>(P, (f16*)tile2_smem);
+    else if (P.kind == WRK_MAT_Q8_0) gemm_tile2_body_q8<TT>(P, (f16*)tile2_smem);
+    else gemm_tile2_body_f16<TT>(P, (f16*)tile2_smem);
 }
 
 __global__ void __launch_bounds__(256) gemm_tile_kernel(const GemmBatch B) {
@@ -1636,7 +1711,9 @@ int matmul_mfma_multi(hipStream_t s, const MatJob* jobs, int njobs, int) {
         // tiles that ride along with the big matrices of their stage; on the K-split kernel they were a 32-us launch of 64 workgroups per layer
         // K4 kinds whose output rows come in fours (one vector store per lane) take the second-generation tile kernel
         // (with few workgroups -- a single 128-token chunk -- the first-generation kernel's longer stages are 4 % faster)
-        if (tile && use_tile2 && n >= 512 && (j.kind == WRK_MAT_Q4_K || j.kind == WRK_MAT_Q5_K || q8_tile2) && (j.m & 3u) == 0) { fill_job(T2.jobs[T2.njobs++], j, n, t2wg); t2wg += (j.m + TILE_ROWS - 1) / TILE_ROWS; }
+        static const bool f16_tile2_on = [] { const char* e = getenv("WRK_GEMM_TILE2_F16"); return !(e && e[0] == '0'); }();
+        const bool f16_tile2 = f16_tile2_on && j.kind == WRK_MAT_F16 && (j.k & 127u) == 0 && (j.row_bytes & 15u) == 0;
+        if (tile && use_tile2 && n >= 512 && (j.kind == WRK_MAT_Q4_K || j.kind == WRK_MAT_Q5_K || q8_tile2 || f16_tile2) && (j.m & 3u) == 0) { fill_job(T2.jobs[T2.njobs++], j, n, t2wg); t2wg += (j.m + TILE_ROWS - 1) / TILE_ROWS; }
         else if (tile) { fill_job(T.jobs[T.njobs++], j, n, twg); twg += (j.m + TILE_ROWS - 1) / TILE_ROWS; }
         else { fill_job(B.jobs[B.njobs++], j, n, wg); wg += (j.m + 15) / 16; kmax = j.k > kmax ? j.k : kmax; }
     }
