@@ -465,8 +465,8 @@ __global__ void __launch_bounds__(256) time_mix_v7_fast_kernel(const uint32_t* _
 #pragma unroll
             for (int jj = 0; jj < 16; ++jj) { kkf[jj] = (float)curT.kk[jj >> 3][jj & 7]; s4[jj & 3] = __builtin_fmaf(Sreg[jj], -kkf[jj], s4[jj & 3]); }   // a~ = -kk
             float sa = (s4[0] + s4[1]) + (s4[2] + s4[3]);
-            sa = (sa + __shfl_xor(sa, 1, WAVE));
-            sa = (sa + __shfl_xor(sa, 2, WAVE));
+            sa = sa + dpp_f32<0xB1>(sa);          // lane ^ 1, lane ^ 2 inside the quad: DPP, not ds_bpermute (an LDS round trip each)
+            sa = sa + dpp_f32<0x4E>(sa);
             const float vv = (float)curT.v;
             float y4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -477,8 +477,8 @@ __global__ void __launch_bounds__(256) time_mix_v7_fast_kernel(const uint32_t* _
                 y4[jj & 3] = __builtin_fmaf((float)curT.r[jj >> 3][jj & 7], sn, y4[jj & 3]);
             }
             float y = (y4[0] + y4[1]) + (y4[2] + y4[3]);
-            y = (y + __shfl_xor(y, 1, WAVE));
-            y = (y + __shfl_xor(y, 2, WAVE));
+            y = y + dpp_f32<0xB1>(y);
+            y = y + dpp_f32<0x4E>(y);
             if (valid && part == 0) *xp = (f16)y;
             xp += valid ? xstep : 0;
             // w~ of the next token (the last token's again at the end of the chunk)
