@@ -719,8 +719,8 @@ __global__ void __launch_bounds__(256) time_mix_v6_fast_kernel(const uint32_t* _
             y += curT.r[jj >> 2][jj & 3] * __builtin_fmaf(uu[jj], kv, Sreg[jj]);
             Sreg[jj] = __builtin_fmaf(curT.w[jj >> 2][jj & 3], Sreg[jj], kv);
         }
-        y = (y + __shfl_xor(y, 1, WAVE));
-        y = (y + __shfl_xor(y, 2, WAVE));
+        y = y + dpp_f32<0xB1>(y);
+        y = y + dpp_f32<0x4E>(y);
         if (part == 0) *xp = (f16)y;
         xp += xstep;
         if (more) curT = nxtT;

@@ -266,8 +266,8 @@ __global__ void __launch_bounds__(256) v6_mix_kernel(const V6MixParams P) {
                 acc = __builtin_amdgcn_fdot2(__builtin_shufflevector(w[i][n], w[i][n], 6, 7), __builtin_shufflevector(xx[i][n], xx[i][n], 6, 7), acc, false);
             }
         }
-        acc += __shfl_xor(acc, 1, WAVE);
-        acc += __shfl_xor(acc, 2, WAVE);
+        acc += dpp_f32<0xB1>(acc);
+        acc += dpp_f32<0x4E>(acc);
         if (part == 0) {
             const float f = r16(r16(acc) + tmv[i]);                                        // matmul (f16 store) + add(time_mix)
             P.sx5[((size_t)i * P.T + t) * D + c] = (f16)wgsl_mix(xl, prev, f);             // token_shift(.., reversed)
@@ -329,8 +329,8 @@ __global__ void __launch_bounds__(256) v6_head_kernel(const V6HeadParams P) {
             acc = __builtin_amdgcn_fdot2(__builtin_shufflevector(w[n], w[n], 6, 7), __builtin_shufflevector(xx[n], xx[n], 6, 7), acc, false);
         }
     }
-    acc += __shfl_xor(acc, 1, WAVE);
-    acc += __shfl_xor(acc, 2, WAVE);
+    acc += dpp_f32<0xB1>(acc);
+    acc += dpp_f32<0x4E>(acc);
     if (part == 0) {
         // time_decay buffer is f32: matmul result unrounded, + time_decay, then activate(StableExp) = exp(-exp(x))
         sh_w[row] = __expf(-__expf(acc + td0));
@@ -347,8 +347,8 @@ __global__ void __launch_bounds__(256) v6_head_kernel(const V6HeadParams P) {
         const float sn = __builtin_fmaf(sh_w[j], Sreg[jj], kv);
         st[(size_t)j * D] = sn;
     }
-    y = (y + __shfl_xor(y, 1, WAVE));
-    y = (y + __shfl_xor(y, 2, WAVE));
+    y = y + dpp_f32<0xB1>(y);
+    y = y + dpp_f32<0x4E>(y);
     if (part == 0) sh_y[i] = r16(y);                                            // aux_x (f16 store)
     __syncthreads();
     if (tid < S) {      // group norm over the head, SiLU gate: thread = column

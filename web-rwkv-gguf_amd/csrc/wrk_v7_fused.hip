@@ -181,8 +181,8 @@ __device__ __forceinline__ float lora_dot(const LoraRegs<MAXCH>& r, uint32_t ran
             acc = __builtin_amdgcn_fdot2(__builtin_shufflevector(r.w[n], r.w[n], 6, 7), __builtin_shufflevector(r.x[n], r.x[n], 6, 7), acc, false);
         }
     }
-    acc += __shfl_xor(acc, 1, WAVE);
-    acc += __shfl_xor(acc, 2, WAVE);
+    acc += dpp_f32<0xB1>(acc);      // lane ^ 1, lane ^ 2 inside the quad by DPP (ds_bpermute = an LDS round trip each on the head kernels' critical path)
+    acc += dpp_f32<0x4E>(acc);
     return acc;
 }
 
