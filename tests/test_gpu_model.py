@@ -277,3 +277,29 @@ def test_concurrent_pipelines_equal_separate_runs(ctx, B, groups):
         ol = oracle.infer_chunk([[t] for t in cur], list(range(B)))
         cur = [int(ol[b].argmax()) for b in range(B)]
         assert toks[step].tolist() == cur, step
+
+
+@pytest.mark.parametrize("B", [9, 20])
+def test_k_sliced_gemm_runs_are_bit_identical(ctx, B, monkeypatch):
+    """Every GEMM of a 9 / 20-sequence decode on the K-sliced kernel (WRK_GEMM_KS=2): its K slices meet in-kernel through write-through
+    partial tiles and arrival counters, added in slice order -- so two runs from the same state must agree bit for bit (a stale tile
+    would not), and the greedy tokens must be the oracle's."""
+    monkeypatch.setenv("WRK_GEMM_KS", "2")
+    data = synth.make_v7_gguf(synth.CONFIGS["small"], 42)
+    V = synth.CONFIGS["small"].num_vocab
+    first = [(5 + 31 * b) % (V - 1) for b in range(B)]
+    runs = []
+    for _ in range(3):
+        rt = wrk.Runtime(ctx, wrk.GgufReader(data), num_batch=B)
+        toks, _, logits = rt.generate_greedy(first, 24, mode=1, want_logits=True)
+        runs.append((toks.copy(), logits.copy(), [rt.state_back(b) for b in range(B)]))
+        rt.close()
+    for toks, logits, states in runs[1:]:
+        assert np.array_equal(toks, runs[0][0]) and np.array_equal(logits, runs[0][1])
+        assert all(np.array_equal(x, y) for x, y in zip(states, runs[0][2]))
+    oracle = O.V7Runtime(O.build_v7(ogguf.GgufReader(data), weights_f16=False), B, act_f16=True)
+    cur = list(first)
+    for step in range(8):
+        ol = oracle.infer_chunk([[t] for t in cur], list(range(B)))
+        cur = [int(ol[b].argmax()) for b in range(B)]
+        assert runs[0][0][step].tolist() == cur, step
