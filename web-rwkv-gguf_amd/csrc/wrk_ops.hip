@@ -456,6 +456,9 @@ __global__ void __launch_bounds__(256) time_mix_v7_fast_kernel(const uint32_t* _
             const bool valid = t < tend;                            // uniform; a masked step changes nothing
             const Tok& curT = T[u];
             __syncthreads();                                        // w~ of token t is in sh_w[t & 1]
+            // w~ of the NEXT token goes into the other buffer right away (its decay arrived a step ago; the last token's again at the end
+            // of the chunk): the exponentials of the one wave that computes it are off the path to the next barrier
+            if (tid < S) sh_w[(t + 1) & 1u][tid] = __expf(-0.606531f * act_sigmoid((float)T[(u + 1) % NPF].wraw));
             const float* wt = sh_w[t & 1u] + part * 16;
             float wv[16];
 #pragma unroll
@@ -481,8 +484,6 @@ __global__ void __launch_bounds__(256) time_mix_v7_fast_kernel(const uint32_t* _
             y = y + dpp_f32<0x4E>(y);
             if (valid && part == 0) *xp = (f16)y;
             xp += valid ? xstep : 0;
-            // w~ of the next token (the last token's again at the end of the chunk)
-            if (tid < S) sh_w[(t + 1) & 1u][tid] = __expf(-0.606531f * act_sigmoid((float)T[(u + 1) % NPF].wraw));
             // this register set is free: request token t + NPF (the last token again once the chunk ends; discarded)
             { const bool adv = lpos + 1 < tend; load_tok(T[u], adv); lpos += adv ? 1u : 0u; }
         }
