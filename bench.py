@@ -285,10 +285,39 @@ def launch_replicas(n, argv):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    for line in out.decode().splitlines():      # the JSON line to stdout; library chatter (e.g. gloo's connection notes) to stderr
-        (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line + "\n")
+    # watch every rank: the first one that dies takes the others down with it (a rank that never reaches the rendezvous would otherwise
+    # leave the rest in init_process_group / the barrier until the backend's own timeout -- minutes -- and the caller's window with it)
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = None
+    while True:
+        rcs = [p.poll() for p in procs]
+        bad = [r for r, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad:
+            failed = bad[0]
+            break
+        if all(rc == 0 for rc in rcs):
+            break
+        time.sleep(0.05)
+    if failed is not None:
+        sys.stderr.write(f"bench.py: rank {failed} exited with code {procs[failed].returncode}; stopping the other ranks\n")
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        deadline = time.time() + 5.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    reader.join(timeout=5.0)
+    rcs = [p.returncode for p in procs]
+    out = b"".join(c for c in chunks if c)
+    for line in out.decode(errors="replace").splitlines():      # the JSON line to stdout; library chatter (e.g. gloo's connection notes) to stderr
+        (sys.stdout if (failed is None and line.lstrip().startswith("{")) else sys.stderr).write(line + "\n")
     sys.stdout.flush()
     if any(rcs):
         sys.stderr.write(f"bench.py: rank exit codes {rcs}\n")
@@ -323,6 +352,8 @@ def main():
     ap.add_argument("--stub-device", action="store_true",
                     help="TEST ONLY (tests/test_bench_launcher.py): exercise the launcher, the rank rendezvous (gloo) and the aggregation "
                          "without a GPU; the decode step is replaced by a sleep and the JSON line is marked \"data\": \"stub\"")
+    ap.add_argument("--rendezvous-timeout", type=float, default=120.0, help="seconds a rank waits for the others in init_process_group / the barriers")
+    ap.add_argument("--stub-fail-rank", type=int, default=-1, help="TEST ONLY: with --stub-device this rank exits with code 3 before the rendezvous")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -333,6 +364,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
+    if args.stub_device and rank == args.stub_fail_rank:
+        sys.stderr.write(f"bench.py: rank {rank} failing on request (--stub-fail-rank)\n")
+        sys.exit(3)
     dist = None
     device = local_rank
     if args.device_map:
@@ -343,11 +377,13 @@ def main():
         import torch.distributed as dist
         if args.force_dist and "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+        import datetime
+        rdv = datetime.timedelta(seconds=args.rendezvous_timeout)      # a missing rank fails the rendezvous in seconds, not in the backend's half hour
         if use_gloo:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=rdv)
         else:
             torch.cuda.set_device(device)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device), timeout=rdv)
 
     sys.path.insert(0, os.path.join(ROOT, "web-rwkv-gguf_amd", "wrk"))
     import replicas         # no GPU dependency (the stub ranks import nothing else of the package)

@@ -285,6 +285,12 @@ int32_t wrk_v7_infer(wrk_ctx* ctx, wrk_v7_model* model, wrk_v7_state* state,
  * (IN_FP32 shader variants), the op-by-op launch list runs whatever `mode` says.  Call between jobs; drops cached programs. */
 int32_t wrk_v7_model_set_frame_dtype(wrk_ctx* ctx, wrk_v7_model* model, uint32_t dtype);
 
+/* The persistent batch-1 decode engine (one launch for all layers of a token; the device-side analogue of the reference's
+ * speculative job queue, runtime/mod.rs:110-209, which keeps the next job ready while the current one runs).  It is built on the
+ * first one-token job of a model and used by mode 1 whenever it exists and WRK_ENGINE != 0.  Returns 1 when the engine exists,
+ * 0 when it does not (reason copied to `why`, NUL-terminated, when why != NULL), < 0 on error.  Builds it if no job has run yet. */
+int32_t wrk_v7_model_engine_status(wrk_ctx* ctx, wrk_v7_model* model, char* why, size_t capacity);
+
 /* Parity instrumentation at the reference's own seam: v7::Hook / HookMap closures receive the `Frame` (state + Runtime<F>
  * buffers) at every stage of a layer (v7.rs:386-421, 497-502) and examples/inspect.rs:100-248 reads each buffer back per layer.
  *   wrk_v7_infer_layer: run ONLY `layer` of a job (mode as wrk_v7_infer) on a caller-supplied layer input x [D, num_token] and

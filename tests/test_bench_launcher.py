@@ -49,3 +49,34 @@ def test_metric_names():
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
     assert bench.metric_name("1.5B", 1, 1) == base              # the headline line carries BASELINE.json's metric string verbatim
     assert "@8 GPU" in bench.metric_name("v6-7B", 16, 8) and "RWKV-6 7B Q5_K_M" in bench.metric_name("v6-7B", 16, 8)
+
+
+def test_a_dying_rank_stops_the_launcher_within_seconds():
+    # rank 1 exits before the rendezvous; the parent must notice, stop rank 0 (which is waiting in init_process_group)
+    # and return non-zero quickly instead of sitting out the backend's timeout
+    import time
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "0", "--stub-device",
+                        "--stub-fail-rank", "1"], env=e, capture_output=True, text=True, timeout=120)
+    took = time.time() - t0
+    assert p.returncode != 0
+    assert "rank 1 exited with code 3" in p.stderr
+    assert not [l for l in p.stdout.splitlines() if l.strip().startswith("{")]       # no result line from a failed run
+    assert took < 60, took
+
+
+def test_stream_partition_of_cfg4():
+    # cfg 4: 128 independent streams over 8 GPUs = 16 per rank, no overlap, no gap; every rank's first tokens follow its GLOBAL stream ids
+    sys.path.insert(0, os.path.join(ROOT, "web-rwkv-gguf_amd", "wrk"))
+    import replicas
+    seen = []
+    parts = replicas.partition_streams(128, 8)
+    for r in range(8):
+        mine = parts[r]
+        assert len(mine) == 16
+        assert mine == [g for g in range(128) if g % 8 == r]        # batch index -> GPU b mod 8
+        first = [(17 + 101 * g) % 65535 for g in mine]          # bench.py's first-token rule
+        assert len(set(first)) == 16
+        seen += mine
+    assert sorted(seen) == list(range(128))

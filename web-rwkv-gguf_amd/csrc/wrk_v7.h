@@ -2,6 +2,7 @@
 #pragma once
 #include <atomic>
 #include <map>
+#include <string>
 #include <tuple>
 #include <vector>
 
@@ -69,6 +70,12 @@ struct wrk_v7_model {
     std::vector<hipStream_t> lane_streams;
     std::vector<hipEvent_t> lane_events;
 
+    // persistent batch-1 decode engine (wrk_v7_engine.hip): built on first use, nullptr when the model / device does not fit it
+    struct wrk_v7_engine* engine = nullptr;
+    bool engine_tried = false;
+    std::string engine_why;             // why the engine is not available (diagnostics)
+    int32_t ensure_engine();            // outside captures; WRK_OK also when the engine is unavailable
+    bool engine_on() const;             // WRK_ENGINE != 0 and the engine exists
     int32_t ensure_scratch(uint32_t T, uint32_t NH);
     int32_t ensure_history(size_t n);
     void drop_graphs();
@@ -81,6 +88,7 @@ struct wrk_v7_model {
 };
 
 int32_t wrk_buf_write_raw(wrk_ctx* ctx, void* dst, const void* src, size_t bytes);
+bool split_head_env_on();     // WRK_SPLIT_HEAD != 0, read per call (part of the graph keys)
 
 namespace wrk {
 // tokens <- argmax; history[counter][b] = argmax[b]; counter += 1   (one tiny kernel)

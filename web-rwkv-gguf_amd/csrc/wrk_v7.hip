@@ -7,6 +7,7 @@
 // contributes exactly one token, and falls back to mode 0 otherwise (prefill chunks).
 #include "wrk_internal.h"
 #include "wrk_v7.h"
+#include "wrk_v7_engine.h"
 
 #define LOCK(ctx) std::lock_guard<std::recursive_mutex> _lk((ctx)->mu)
 
@@ -281,6 +282,8 @@ int32_t wrk_v7_model::enqueue_ops(wrk_v7_state* st, uint32_t T, uint32_t NH, boo
 }
 
 // ------------------------------------------------------------------ C ABI
+bool split_head_env_on() { const char* e = getenv("WRK_SPLIT_HEAD"); return !(e && e[0] == '0'); }
+
 extern "C" {
 
 int32_t wrk_v7_model_create(wrk_ctx* ctx, const wrk_v7_model_desc* desc, wrk_v7_model** out) {
@@ -340,6 +343,8 @@ int32_t wrk_v7_model_destroy(wrk_v7_model* m) {
         for (auto& kv : m->graphs) wrk_program_destroy(kv.second);
         if (m->scratch) hipFree(m->scratch);
         m->free_fused();
+        wrk_v7_engine_destroy(m->engine);
+        m->engine = nullptr;
         for (hipStream_t s : m->lane_streams) { hipStreamSynchronize(s); hipStreamDestroy(s); }
         for (hipEvent_t e : m->lane_events) hipEventDestroy(e);
         m->lane_streams.clear(); m->lane_events.clear();
@@ -490,6 +495,7 @@ int32_t wrk_v7_infer(wrk_ctx* ctx, wrk_v7_model* m, wrk_v7_state* st, const uint
     }
     int32_t rc = m->ensure_scratch(T, NH ? NH : 1);
     if (rc != WRK_OK) return rc;
+    if (T == 1 && mode == 1) { rc = m->ensure_engine(); if (rc != WRK_OK) return rc; }
     rc = wrk_buf_write_raw(ctx, m->s.cursors, cursors, (size_t)T * 4);
     if (rc != WRK_OK) return rc;
     if (NH) { rc = wrk_buf_write_raw(ctx, m->s.headers, headers, (size_t)NH * 4); if (rc != WRK_OK) return rc; }
@@ -519,7 +525,8 @@ int32_t wrk_v7_infer(wrk_ctx* ctx, wrk_v7_model* m, wrk_v7_state* st, const uint
     else {
         // bit 5: a non-fused job enqueues the merged launch list in mode 1 and the reference op list in mode 0 -- two graphs
         const uint32_t flags = 16u | (m->act_dtype == WRK_F32 ? 64u : 0u) | (fused ? 1u : 0u) | (identity ? 2u : 0u) | (tokens ? 4u : 0u) | ((NH && argmax) ? 8u : 0u) |
-                               ((!fused && mode == 1) ? 32u : 0u) | (fused ? (cursors[0] & 0xffu) << 8 : 0u) | ((fused && contiguous) ? 1u << 16 : 0u);
+                               ((!fused && mode == 1) ? 32u : 0u) | (fused ? (cursors[0] & 0xffu) << 8 : 0u) | ((fused && contiguous) ? 1u << 16 : 0u) |
+                               ((fused && T == 1 && m->engine_on()) ? 1u << 17 : 0u) | (split_head_env_on() ? 0u : 1u << 18);
         const wrk_v7_model::GraphKey key{st->uid, T, flags, NH};
         wrk_program* prog = nullptr;
         auto it = m->graphs.find(key);
@@ -545,7 +552,7 @@ int32_t wrk_v7_infer(wrk_ctx* ctx, wrk_v7_model* m, wrk_v7_state* st, const uint
     if (NH && logits) WRK_HIP(ctx, hipMemcpyAsync(logits, m->s.head_o, (size_t)NH * V * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (NH && argmax) WRK_HIP(ctx, hipMemcpyAsync(argmax, m->s.argmax, (size_t)NH * 4, hipMemcpyDeviceToHost, ctx->stream));
     WRK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return WRK_OK;
+    return wrk_v7_engine_check(m->engine);
 }
 
 // Bundle::<F>::new (v7.rs:514-536): the activation type of the frame.  F16 is the reference's default build
@@ -563,7 +570,27 @@ int32_t wrk_v7_model_set_frame_dtype(wrk_ctx* ctx, wrk_v7_model* m, uint32_t dty
     m->scratch = nullptr;
     m->scratch_tokens = m->scratch_headers = 0;
     m->act_dtype = dtype;
+    // the concurrent-pipeline lanes carry the frame type they were created with (and programs captured for it): drop them, the next
+    // generate_greedy(groups > 1) rebuilds them with the new type
+    for (hipStream_t ls : m->lane_streams) WRK_HIP(ctx, hipStreamSynchronize(ls));
+    std::vector<wrk_v7_model*> old_lanes;
+    old_lanes.swap(m->lanes);
+    for (wrk_v7_model* lane : old_lanes) wrk_v7_model_destroy(lane);
     return WRK_OK;
+}
+
+int32_t wrk_v7_model_engine_status(wrk_ctx* ctx, wrk_v7_model* m, char* why, size_t capacity) {
+    if (!ctx || !m) return WRK_E_ARG;
+    LOCK(ctx);
+    WRK_HIP(ctx, hipSetDevice(ctx->device));
+    WRK_ARG(ctx, !ctx->capturing_here(), "not inside a capture");
+    const int32_t rc = m->ensure_engine();
+    if (rc != WRK_OK) return rc;
+    if (why && capacity) {
+        const std::string& w = m->engine ? std::string() : (m->engine_tried ? m->engine_why : std::string("disabled (WRK_ENGINE=0 or f32 frames)"));
+        snprintf(why, capacity, "%s", w.c_str());
+    }
+    return m->engine ? 1 : 0;
 }
 
 // Teacher-forced run of ONE layer (parity tests; the reference reaches the same buffers through v7::HookMap closures over
@@ -593,6 +620,7 @@ int32_t wrk_v7_infer_layer(wrk_ctx* ctx, wrk_v7_model* m, wrk_v7_state* st, uint
     for (uint32_t t = 1; t < T; ++t) contiguous = contiguous && (cursors[t] & 0xff) == (cursors[0] & 0xff) + t;
     int32_t rc = m->ensure_scratch(T, 1);
     if (rc != WRK_OK) return rc;
+    if (T == 1 && mode == 1) { rc = m->ensure_engine(); if (rc != WRK_OK) return rc; }
     const size_t esz = m->act_dtype == WRK_F32 ? 4 : 2;
     rc = wrk_buf_write_raw(ctx, m->s.cursors, cursors, (size_t)T * 4);
     if (rc == WRK_OK) rc = wrk_buf_write_raw(ctx, m->s.x, x, (size_t)T * m->d.num_emb * esz);
@@ -605,7 +633,7 @@ int32_t wrk_v7_infer_layer(wrk_ctx* ctx, wrk_v7_model* m, wrk_v7_state* st, uint
     if (rc != WRK_OK) return rc;
     WRK_LAUNCH_CHECK(ctx);
     WRK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return WRK_OK;
+    return wrk_v7_engine_check(m->engine);
 }
 
 // TensorGpu::back on one buffer of the frame (names as examples/inspect.rs:208-248: x, att_x, att_r, ..., ffn_v; plus head_x, head_o)
@@ -642,6 +670,7 @@ static int32_t greedy_prepare(wrk_ctx* ctx, wrk_v7_model* m, wrk_v7_state* st, c
     const uint32_t D = m->d.num_emb, V = m->d.num_vocab;
     int32_t rc = m->ensure_scratch(B, B);
     if (rc != WRK_OK) return rc;
+    if (B == 1 && mode == 1) { rc = m->ensure_engine(); if (rc != WRK_OK) return rc; }
     rc = m->ensure_history((size_t)steps * B);
     if (rc != WRK_OK) return rc;
     std::vector<uint32_t> cur(B), hdr(B);
@@ -655,7 +684,8 @@ static int32_t greedy_prepare(wrk_ctx* ctx, wrk_v7_model* m, wrk_v7_state* st, c
     *prog_out = nullptr;
     if (eager) return WRK_OK;
     // one graph per (state, first sequence, B, mode): the analogue of the reference's cached RnnJob for a repeated RnnInfo
-    const wrk_v7_model::GraphKey key{st->uid, B | (b0 << 16), mode | (m->act_dtype == WRK_F32 ? 4u : 0u)};
+    const wrk_v7_model::GraphKey key{st->uid, B | (b0 << 16), mode | (m->act_dtype == WRK_F32 ? 4u : 0u) | ((B == 1 && mode == 1 && m->engine_on()) ? 8u : 0u) |
+                                                             (split_head_env_on() ? 0u : 16u)};
     auto it = m->graphs.find(key);
     if (it != m->graphs.end()) { *prog_out = it->second; return WRK_OK; }
     rc = wrk_capture_begin(ctx);
@@ -774,10 +804,30 @@ int32_t wrk_v7_generate_greedy(wrk_ctx* ctx, wrk_v7_model* m, wrk_v7_state* st, 
     }
     WRK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     wrk::timing_report(ctx);
+    for (uint32_t g = 0; g < groups; ++g) {
+        wrk_v7_engine_report(L[g].mdl->engine);
+        const int32_t rc = wrk_v7_engine_check(L[g].mdl->engine);
+        if (rc != WRK_OK) return rc;
+    }
     return WRK_OK;
 }
 
 }  // extern "C"
+
+// Persistent decode engine: built once, outside captures.  WRK_ENGINE=0 keeps the five-launch layer (read per call, part of the
+// graph key: tests compare the two paths in one process).
+static bool engine_env_on() { const char* e = getenv("WRK_ENGINE"); return !(e && e[0] == '0'); }
+bool wrk_v7_model::engine_on() const { return engine != nullptr && engine_env_on() && act_dtype == WRK_F16; }
+int32_t wrk_v7_model::ensure_engine() {
+    if (engine_tried || !engine_env_on() || act_dtype != WRK_F16) return WRK_OK;
+    if (ctx->capturing_here()) return WRK_OK;       // allocations are not capturable: the caller's program keeps the launches
+    engine_tried = true;
+    const std::string keep = ctx->err;
+    const int32_t rc = wrk_v7_engine_create(this, &engine);
+    if (rc != WRK_OK) { engine = nullptr; engine_why = ctx->err; ctx->err = keep; }
+    if (rc != WRK_OK && rc != WRK_E_UNSUPPORTED) return rc;
+    return WRK_OK;
+}
 
 int32_t wrk_v7_model::ensure_history(size_t n) {
     if (n <= history_cap && history) return WRK_OK;

@@ -1,0 +1,963 @@
+// Persistent batch-1 decode engine for RWKV-7 on gfx950: ALL layers of one decode token in ONE launch, one workgroup per CU.
+//
+// Why: at batch 1 a layer is five dependent all-to-all steps; as five launches each of them costs a
+// kernel boundary (~1.7 us) plus the next kernel's cold start (job struct, input vector, and only THEN the weight stream): 25 us for
+// 38 MB, 18.7 % of the HBM roofline.  tools/probe/allgather_probe.hip measured the alternative on this chip: an in-launch all-to-all of a
+// 4 KB vector through data-tagged granules (8-byte {payload, tag} written by one `sc1` store, re-read with `sc1` loads until every tag
+// matches; no fence, no counter) costs 1.9 us, and it costs the SAME with a weight stream in flight if -- and only if -- the waves that
+// poll are not the waves that stream (vector memory returns in issue order per wave).
+//
+// Structure.  384 threads: waves 0-3 compute (the thread mapping of the five-launch kernels: results are bit-identical to mode 1 with
+// WRK_SPLIT_HEAD=0), wave 4 gathers (sweeps the granules of the next stage's input into LDS), wave 5 loads (streams this CU's slice of
+// every stage's weights into LDS with LDS-DMA, `global_load_lds_dwordx4 ... nt`, a whole layer ahead: 148 KB of weights per CU and layer
+// against 160 KB of LDS -- the round trip to HBM is off every one of the 120 dependent stages of a token).  The reference's analogue is
+// the speculative job queue that hides the host's encode time behind the device (runtime/mod.rs:110-209); here it is the device's
+// weight stream that runs ahead of the dependency chain.
+//
+// Stages of a layer (v7.rs:716-1007; the op list and rounding points of wrk_v7_fused.hip):
+//   K1  LN1 + token shift -> r, k, v (quantised) + w1 (tanh) a1 g1 (sigmoid) v1          all workgroups, rows split by bytes
+//   K2  LoRA up-projections, decay, kk, control_k, value lerp, WKV7, group norm, bonus, gate   one workgroup per head
+//   K3  x += W_o . o                                                                      all workgroups
+//   K5  LN2 + token shift -> relu(ffn key)^2                                              all workgroups
+//   K6  x += ffn value . k ; ffn shift state ; (x *= 0.5 every `rescale` layers)           all workgroups, K over the 4 waves
+// Hand-offs: K1 -> K2 (LoRA intermediates to every head, r / k / v to their head), K2 -> K3, K3 -> K5, K5 -> K6, K6 -> next K1.
+//
+// Safety: every spin is bounded; a give-up raises a device flag, the workgroup leaves at its next barrier, its consumers give up in
+// turn, and the host reports WRK_E_HIP at the next synchronisation.  The grid is one workgroup per CU and needs all of them resident
+// (LDS > 80 KB: exactly one per CU): the host refuses to build the engine otherwise.
+#include "wrk_device.h"
+#include "wrk_v7.h"
+#include "wrk_dmv_body.h"
+#include "wrk_v7_engine.h"
+#include "wrk_lora_dev.h"
+
+#include <algorithm>
+#include <string>
+
+namespace wrk {
+
+#define ENG_LDS __attribute__((address_space(3)))
+typedef ENG_LDS unsigned char lds_u8;
+
+// workgroup barrier for all three roles: LDS traffic of this wave has landed, then s_barrier.  (Not __syncthreads(): its fences make the
+// compiler drain vmcnt for pending LDS-DMA, and the roles must execute the same NUMBER of barrier instructions, nothing more.)
+#define ENG_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+constexpr uint32_t ENG_SPIN_MAX = 1u << 21;
+
+__device__ __forceinline__ uint32_t eng_tag(uint32_t layer, uint32_t stage) { return layer * 8u + stage + 1u; }
+
+__device__ __forceinline__ void eng_store_granule(unsigned long long* g, uint32_t tag, uint32_t payload) {
+    __hip_atomic_store(g, ((unsigned long long)tag << 32) | payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // global_store_dwordx2 sc1
+}
+__device__ __forceinline__ uint32_t pack_h2(float a, float b) {
+    const f16x2 h = {(f16)a, (f16)b};
+    return __builtin_bit_cast(uint32_t, h);
+}
+
+// ------------------------------------------------------------------ gather wave
+// Sweep `n16` 16-byte pieces (two granules each) at `g` until every tag equals `tag`; the two payload dwords of piece q go to dst[2q],
+// dst[2q + 1].  Eight loads per lane and pass, consecutive lanes on consecutive pieces.  false: gave up.
+__device__ __forceinline__ bool eng_gather(const unsigned long long* g, uint32_t n16, uint32_t tag, ENG_LDS uint32_t* dst, uint32_t lane) {
+    for (uint32_t base = 0; base < n16; base += 512) {
+        const u32x4* p[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) p[i] = (const u32x4*)g + min(base + lane + 64u * i, n16 - 1);
+        u32x4 v[8];
+        bool good = false;
+        for (uint32_t spins = 0; spins < ENG_SPIN_MAX; ++spins) {
+            asm volatile(
+                "global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %9, off sc1\n\tglobal_load_dwordx4 %2, %10, off sc1\n\t"
+                "global_load_dwordx4 %3, %11, off sc1\n\tglobal_load_dwordx4 %4, %12, off sc1\n\tglobal_load_dwordx4 %5, %13, off sc1\n\t"
+                "global_load_dwordx4 %6, %14, off sc1\n\tglobal_load_dwordx4 %7, %15, off sc1\n\ts_waitcnt vmcnt(0)"
+                : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+                : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7])
+                : "memory");
+            bool ok = true;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ok &= (v[i].y == tag) & (v[i].w == tag);
+            if (__all(ok)) { good = true; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (!good) return false;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t q = base + lane + 64u * i;
+            if (q < n16) { dst[2 * q] = v[i].x; dst[2 * q + 1] = v[i].z; }
+        }
+    }
+    return true;
+}
+
+// plain copy of n16 16-byte pieces (the launch's input vector, written by an earlier kernel)
+__device__ __forceinline__ void eng_copy_in(const void* src, uint32_t n16, ENG_LDS u32x4* dst, uint32_t lane) {
+    for (uint32_t q = lane; q < n16; q += 64) dst[q] = ((const u32x4*)src)[q];
+}
+
+// ------------------------------------------------------------------ loader wave
+// `bytes` of weights at `src` (16-byte aligned, a multiple of 16) -> LDS at byte offset lds_off, in 1 KiB pieces; lanes beyond the end
+// re-read the last 16 bytes into the slot's padding.  Returns the number of pieces issued.
+__device__ __forceinline__ uint32_t eng_fill(const uint8_t* src, uint32_t bytes, lds_u8* smem, uint32_t lds_off, uint32_t lane) {
+    if (bytes == 0) return 0;
+    const uint32_t np = (bytes + 1023u) >> 10;
+    for (uint32_t p = 0; p < np; ++p) {
+        const uint32_t off = min(p * 1024u + lane * 16u, bytes - 16u);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off), (ENG_LDS void*)(smem + lds_off + p * 1024u), 16, 0, 2);
+    }
+    return np;
+}
+// wait until at most n vector-memory operations of this wave are outstanding (rounded down to a multiple of 8: an immediate operand)
+__device__ __forceinline__ void eng_wait_vm(uint32_t n) {
+    if (n >= 56) asm volatile("s_waitcnt vmcnt(56)" ::: "memory");
+    else if (n >= 48) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+    else if (n >= 40) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+    else if (n >= 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    else if (n >= 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else if (n >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ------------------------------------------------------------------ compute waves: weights and inputs from LDS
+template <int KIND>
+__device__ __forceinline__ Raw lds_raw(const lds_u8* row, uint32_t k, uint32_t c) {
+    Raw r;
+    r.w = *(const ENG_LDS u32x4*)(row + c * 16u);
+    r.a = (u32x4){0, 0, 0, 0};
+    r.b = (u32x2){0, 0};
+    const uint32_t nb = k >> 8, b = c >> 3;
+    if (KIND == WRK_MAT_Q4_K) {
+        r.a.x = *(const ENG_LDS uint32_t*)(row + (nb * 128u + b * 4u));
+        r.a.y = *(const ENG_LDS uint32_t*)(row + (nb * 132u + b * 16u + ((c & 7u) >> 1) * 4u));
+    }
+    return r;
+}
+
+template <int KIND>
+__device__ __forceinline__ XRegs lds_x(const ENG_LDS f16* x, uint32_t c) {
+    XRegs r;
+    const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    r.v[0] = r.v[1] = r.v[2] = r.v[3] = z;
+    r.s[0] = r.s[1] = 0.0f;
+    uint32_t lo, hi;
+    chunk_xoff<KIND>(c, lo, hi);
+    r.v[0] = *(const ENG_LDS f16x8*)(x + lo);
+    if (KIND != WRK_MAT_F16) {
+        r.v[1] = *(const ENG_LDS f16x8*)(x + lo + 8);
+        r.v[2] = *(const ENG_LDS f16x8*)(x + hi);
+        r.v[3] = *(const ENG_LDS f16x8*)(x + hi + 8);
+    }
+    return r;
+}
+
+// lora_dot (wrk_lora_dev.h) with the token's LoRA intermediate read from LDS chunk by chunk (same products, same order)
+template <int MAXCH>
+__device__ __forceinline__ float eng_lora_dot(const f16x8 (&w)[MAXCH], const ENG_LDS f16* aux, uint32_t rank, uint32_t part) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int n = 0; n < MAXCH; ++n) {
+        const uint32_t c = part * 8 + 32 * n;
+        if (c < rank) {
+            const f16x8 x = *(const ENG_LDS f16x8*)(aux + c);
+            acc = __builtin_amdgcn_fdot2(__builtin_shufflevector(w[n], w[n], 0, 1), __builtin_shufflevector(x, x, 0, 1), acc, false);
+            acc = __builtin_amdgcn_fdot2(__builtin_shufflevector(w[n], w[n], 2, 3), __builtin_shufflevector(x, x, 2, 3), acc, false);
+            acc = __builtin_amdgcn_fdot2(__builtin_shufflevector(w[n], w[n], 4, 5), __builtin_shufflevector(x, x, 4, 5), acc, false);
+            acc = __builtin_amdgcn_fdot2(__builtin_shufflevector(w[n], w[n], 6, 7), __builtin_shufflevector(x, x, 6, 7), acc, false);
+        }
+    }
+    acc += dpp_f32<0xB1>(acc);
+    acc += dpp_f32<0x4E>(acc);
+    return acc;
+}
+
+// what the epilogue of a row does with its dot product
+struct EngFin {
+    uint32_t act;           // activation
+    float scale;            // wrk_matrix::out_scale
+    const ENG_LDS f16* res; // residual vector (indexed by row), or nullptr
+    float post;             // multiplied in after the residual add (rescale), 1 otherwise
+};
+__device__ __forceinline__ float eng_finish(const EngFin& f, uint32_t row, float v) {
+    float o = act_apply(f.act, v * f.scale);
+    if (f.res) o = r16(o) + (float)f.res[row];
+    return o;
+}
+
+// Rows [r_begin, r_end) of the slot (relative to the workgroup's first row `row0`), one wave per row, lane L owns chunks L, L + 64, ...
+// of every row (KS == 1) -- dmv_body's arithmetic with LDS-resident weights.  Rows are taken four at a time; lane 0 publishes rows
+// (0, 1) of a batch as one granule, lane 1 rows (2, 3).  `gidx(row)` = granule index of the pair that starts at `row`.
+template <int KIND, bool R16, int XI, int RB, class GIDX>
+__device__ __forceinline__ void eng_rows(const lds_u8* slot, uint32_t row_bytes, uint32_t K, const ENG_LDS f16* xs, uint32_t row0, uint32_t r_begin,
+                                         uint32_t r_end, const EngFin& fin, unsigned long long* gran, uint32_t tag, GIDX gidx, f16* plain_out, uint32_t lane) {
+    if (r_begin >= r_end) return;
+    const uint32_t kpad = (K + 15u) & ~15u;
+    const uint32_t nch = num_chunks<KIND>(K, kpad);
+    XRegs x[1][XI];
+#pragma unroll
+    for (int ci = 0; ci < XI; ++ci) {
+        const uint32_t c = lane + 64u * ci;
+        x[0][ci] = lds_x<KIND>(xs, min(c, nch - 1));
+        if (c >= nch) {
+            const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            x[0][ci].v[0] = x[0][ci].v[1] = x[0][ci].v[2] = x[0][ci].v[3] = z;
+        }
+        x_sums<KIND>(x[0][ci]);
+    }
+    static_assert(RB == 2 || RB == 4, "rows per batch");
+    for (uint32_t ri = r_begin; ri < r_end; ri += RB) {
+        Raw raw[RB][XI];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            const lds_u8* rowp = slot + (size_t)min(ri + rb, r_end - 1) * row_bytes;
+#pragma unroll
+            for (int ci = 0; ci < XI; ++ci) raw[rb][ci] = lds_raw<KIND>(rowp, K, min(lane + 64u * ci, nch - 1));
+        }
+        float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            float acc[1] = {0.0f};
+#pragma unroll
+            for (int ci = 0; ci < XI; ++ci) dot_raw_tokens<KIND, R16, 1, XI>(raw[rb][ci], min(lane + 64u * ci, nch - 1), x, ci, acc);
+            v[rb] = wave_sum(acc[0]);
+        }
+        if (lane < RB / 2) {
+            const uint32_t ra = ri + 2 * lane;              // first row of this lane's pair (rows come in pairs: host-checked)
+            if (ra < r_end) {
+                const float o0 = eng_finish(fin, row0 + ra, lane ? v[2] : v[0]) * fin.post;
+                const float o1 = eng_finish(fin, row0 + ra + 1, lane ? v[3] : v[1]) * fin.post;
+                eng_store_granule(gran + gidx(row0 + ra), tag, pack_h2(o0, o1));
+                if (plain_out) { plain_out[row0 + ra] = (f16)o0; plain_out[row0 + ra + 1] = (f16)o1; }
+            }
+        }
+    }
+}
+
+// LN + token shift of the layer input (dmv_body PRO 1, one input vector): x (LDS, f16) -> xs = mix(LN(x), prev, mixw), ln_out = LN(x).
+// Two barriers inside.  VPT vectors of 8 channels per thread.
+template <int VPT>
+__device__ __forceinline__ void eng_ln_mix(const ENG_LDS f16* xraw, ENG_LDS f16* xs, ENG_LDS f16* ln_out, ENG_LDS float* red, uint32_t K, float eps,
+                                           const f16x8 (&wv)[VPT], const f16x8 (&bv)[VPT], const f16x8 (&mv)[VPT], const f32x4 (&pv)[VPT][2],
+                                           uint32_t tid, uint32_t lane, uint32_t wave) {
+    const uint32_t nvec = K >> 3;
+    f16x8 xv[VPT];
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) xv[v] = *(const ENG_LDS f16x8*)(xraw + min(tid + 256u * v, nvec - 1) * 8);
+    const float c0 = (float)xraw[0];
+    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int v = 0; v < VPT; ++v)
+        if (tid + 256u * v < nvec)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float dl = (float)xv[v][e] - c0; s1 += dl; s2 = __builtin_fmaf(dl, dl, s2); }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (lane == 0) { red[wave] = s1; red[4 + wave] = s2; }
+    ENG_BAR();
+    const float a1 = (red[0] + red[1]) + (red[2] + red[3]);
+    const float a2 = (red[4] + red[5]) + (red[6] + red[7]);
+    const float md = a1 / (float)K;
+    const float mean = c0 + md;
+    const float dev = 1.0f / sqrtf(fmaxf(a2 / (float)K - md * md, 0.0f) + eps);
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) {
+        const uint32_t i = tid + 256u * v;
+        if (i >= nvec) continue;
+        f16x8 yv, o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            yv[e] = (f16)__builtin_fmaf(((float)xv[v][e] - mean) * dev, (float)wv[v][e], (float)bv[v][e]);
+            o[e] = (f16)wgsl_mix((float)yv[e], pv[v][e >> 2][e & 3], (float)mv[v][e]);
+        }
+        *(ENG_LDS f16x8*)(xs + i * 8) = o;
+        *(ENG_LDS f16x8*)(ln_out + i * 8) = yv;
+    }
+    ENG_BAR();
+}
+
+// ------------------------------------------------------------------ the kernel
+// XD: 16-byte chunks per lane of a D-wide quantised row (D <= 2048 XD); R16: WRK_MATRIX_ROUND_F16; QK: kind of the big matrices
+template <int XD, bool R16, int QK>
+__global__ void __launch_bounds__(ENG_THREADS) v7_engine_kernel(const EngArgs A, const uint32_t* __restrict__ wg_head) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char eng_smem_generic[];
+    lds_u8* smem = (lds_u8*)eng_smem_generic;
+    const EngShape& S = A.S;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const uint32_t wg = blockIdx.x;
+    const uint32_t D = S.D, F = S.F;
+    const uint32_t head = wg_head[wg];
+    const bool is_head = head != ENG_NO_HEAD;
+    ENG_LDS uint32_t* abort_flag = (ENG_LDS uint32_t*)(smem + S.lds_misc + 1008);
+    ENG_LDS float* red = (ENG_LDS float*)(smem + S.lds_misc);                // 8 floats
+    ENG_LDS float* part = (ENG_LDS float*)(smem + S.lds_misc + 64);          // 32 rows x 4 waves
+    ENG_LDS f16* xraw0 = (ENG_LDS f16*)(smem + S.lds_xraw0);
+    ENG_LDS f16* xraw1 = (ENG_LDS f16*)(smem + S.lds_xraw1);
+    ENG_LDS f16* xs = (ENG_LDS f16*)(smem + S.lds_xs);                       // also the first D elements of the ffn vector
+    ENG_LDS f16* lnbuf = (ENG_LDS f16*)(smem + S.lds_ln);
+    // K2 scratch, behind xs inside the ffn vector's region
+    ENG_LDS f16* auxbuf = (ENG_LDS f16*)(smem + S.lds_xs + D * 2u);          // aux_w | aux_a | aux_g | aux_v | r[64] k[64] v[64]
+    const uint32_t naux = S.rw + S.ra + S.rg + S.rv;
+    ENG_LDS float* k2f = (ENG_LDS float*)(smem + S.lds_xs + D * 2u + ((naux + 192u) * 2u + 15u & ~15u));      // 8 x 64 + 4 x 64 floats
+
+    // this workgroup's share of every stage
+    uint32_t j1 = ENG_K1_JOBS;
+#pragma unroll
+    for (int j = 0; j < ENG_K1_JOBS; ++j)
+        if (wg >= S.k1[j].wg0 && wg < S.k1[j].wg0 + S.k1[j].nwg) j1 = j;
+    const uint32_t k1_row0 = j1 < ENG_K1_JOBS ? (wg - S.k1[j1].wg0) * S.k1[j1].rows_per_wg : 0u;
+    const uint32_t k1_rows = j1 < ENG_K1_JOBS ? min(S.k1[j1].rows_per_wg, S.k1[j1].rows - k1_row0) : 0u;
+    const uint32_t k1_rb = j1 < ENG_K1_JOBS ? S.k1[j1].row_bytes : 0u;
+    const uint32_t k3_row0 = wg * S.k3_rpw, k3_rows = k3_row0 < D ? min(S.k3_rpw, D - k3_row0) : 0u;
+    const uint32_t k5_row0 = wg * S.k5_rpw, k5_rows = k5_row0 < F ? min(S.k5_rpw, F - k5_row0) : 0u;
+    const uint32_t k6_row0 = wg * S.k6_rpw, k6_rows = k6_row0 < D ? min(S.k6_rpw, D - k6_row0) : 0u;
+    const uint32_t srows = S.state_rows;
+    auto layer_state = [&](uint32_t l) { return A.state + ((size_t)l * A.num_batch + S.batch) * srows * D; };
+    auto k1_src = [&](const EngLayer& L) -> const uint8_t* {
+        const uint8_t* base = j1 == 0 ? L.w_r : j1 == 1 ? L.w_k : j1 == 2 ? L.w_v : j1 == 3 ? L.w1 : j1 == 4 ? L.a1 : j1 == 5 ? L.g1 : L.v1;
+        return base + (size_t)k1_row0 * k1_rb;
+    };
+    auto k1_active = [&](uint32_t l) { return j1 < ENG_K1_JOBS && !(j1 == 6 && l == 0) && k1_rows > 0; };
+#define ENG_STAMP(l, k)                                                                                                            \
+    do {                                                                                                                           \
+        if (A.stamps && (l) == A.stamp_layer && lane == 0) A.stamps[((size_t)wg * 6 + wave) * ENG_STAMPS + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+
+    if (tid == 0) *abort_flag = 0;
+    ENG_BAR();
+
+    // ================================================================== loader wave
+    if (wave == 5) {
+        uint32_t issued = 0, m1 = 0, m3 = 0, m5 = 0, m6 = 0;
+        auto fill1 = [&](uint32_t l) { const EngLayer& L = A.layers[l]; issued += eng_fill(k1_src(L), k1_active(l) ? k1_rows * k1_rb : 0u, smem, S.lds_slot1, lane); m1 = issued; };
+        auto fill3 = [&](uint32_t l) { const EngLayer& L = A.layers[l]; issued += eng_fill(L.w_o + (size_t)k3_row0 * S.rb_d, k3_rows * S.rb_d, smem, S.lds_slot3, lane); m3 = issued; };
+        auto fill5 = [&](uint32_t l) { const EngLayer& L = A.layers[l]; issued += eng_fill(L.ffn_k + (size_t)k5_row0 * S.rb_d, k5_rows * S.rb_d, smem, S.lds_slot5, lane); m5 = issued; };
+        auto fill6 = [&](uint32_t l) { const EngLayer& L = A.layers[l]; issued += eng_fill(L.ffn_v + (size_t)k6_row0 * S.rb_f, k6_rows * S.rb_f, smem, S.lds_slot6, lane); m6 = issued; };
+        fill1(S.layer_begin); fill3(S.layer_begin); fill5(S.layer_begin); fill6(S.layer_begin);
+        for (uint32_t l = S.layer_begin; l < S.layer_end; ++l) {
+            const bool more = l + 1 < S.layer_end;
+            // K1
+            eng_wait_vm(issued - m1);
+            ENG_BAR();
+            if (*abort_flag) break;
+            ENG_BAR(); ENG_BAR(); ENG_BAR();
+            ENG_STAMP(l, 0);
+            if (more) fill1(l + 1);
+            // K2
+            if (is_head) { ENG_BAR(); if (*abort_flag) break; ENG_BAR(); ENG_BAR(); ENG_BAR(); ENG_BAR(); ENG_BAR(); ENG_BAR(); }
+            // K3
+            eng_wait_vm(issued - m3);
+            ENG_BAR();
+            if (*abort_flag) break;
+            ENG_BAR();
+            if (more) fill3(l + 1);
+            // K5
+            eng_wait_vm(issued - m5);
+            ENG_BAR();
+            if (*abort_flag) break;
+            ENG_BAR(); ENG_BAR(); ENG_BAR();
+            if (more) fill5(l + 1);
+            // K6
+            eng_wait_vm(issued - m6);
+            ENG_BAR();
+            if (*abort_flag) break;
+            ENG_BAR(); ENG_BAR();
+            if (more) fill6(l + 1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+
+    // ================================================================== gather wave
+    if (wave == 4) {
+        for (uint32_t l = S.layer_begin; l < S.layer_end; ++l) {
+            bool ok = true;
+            // K1: the layer input
+            if (l == S.layer_begin) eng_copy_in(A.x_in, D >> 3, (ENG_LDS u32x4*)xraw0, lane);
+            else ok = eng_gather(A.gran + S.g_x, D >> 2, eng_tag(l - 1, 4), (ENG_LDS uint32_t*)xraw0, lane);
+            if (!ok && lane == 0) { *abort_flag = 1; atomicOr(A.fail, 1u); }
+            ENG_STAMP(l, 0);
+            ENG_BAR();
+            if (*abort_flag) break;
+            ENG_BAR(); ENG_BAR(); ENG_BAR();
+            // K2: LoRA intermediates + this head's r, k, v
+            if (is_head) {
+                // (layer 0 has no value-residual LoRA: its granules are never written there)
+                ok = eng_gather(A.gran + S.g_k1, (l == 0 ? naux - S.rv : naux) >> 2, eng_tag(l, 0), (ENG_LDS uint32_t*)auxbuf, lane);
+                if (ok) ok = eng_gather(A.gran + S.g_k1 + S.g_aux + head * 96u, 48u, eng_tag(l, 0), (ENG_LDS uint32_t*)(auxbuf + naux), lane);
+                if (!ok && lane == 0) { *abort_flag = 1; atomicOr(A.fail, 2u); }
+                ENG_STAMP(l, 1);
+                ENG_BAR();
+                if (*abort_flag) break;
+                ENG_BAR(); ENG_BAR(); ENG_BAR(); ENG_BAR(); ENG_BAR(); ENG_BAR();
+            }
+            // K3: the gated head outputs
+            ok = eng_gather(A.gran + S.g_o, D >> 2, eng_tag(l, 1), (ENG_LDS uint32_t*)xs, lane);
+            if (!ok && lane == 0) { *abort_flag = 1; atomicOr(A.fail, 4u); }
+            ENG_STAMP(l, 2);
+            ENG_BAR();
+            if (*abort_flag) break;
+            ENG_BAR();
+            // K5: x after the time mix
+            ok = eng_gather(A.gran + S.g_x1, D >> 2, eng_tag(l, 2), (ENG_LDS uint32_t*)xraw1, lane);
+            if (!ok && lane == 0) { *abort_flag = 1; atomicOr(A.fail, 8u); }
+            ENG_STAMP(l, 3);
+            ENG_BAR();
+            if (*abort_flag) break;
+            ENG_BAR(); ENG_BAR(); ENG_BAR();
+            // K6: the ffn vector
+            ok = eng_gather(A.gran + S.g_k, F >> 2, eng_tag(l, 3), (ENG_LDS uint32_t*)xs, lane);
+            if (!ok && lane == 0) { *abort_flag = 1; atomicOr(A.fail, 16u); }
+            ENG_STAMP(l, 4);
+            ENG_BAR();
+            if (*abort_flag) break;
+            ENG_BAR(); ENG_BAR();
+        }
+        return;
+    }
+
+    // ================================================================== compute waves (256 threads)
+    constexpr int VPT = XD;                                 // vectors of 8 channels per thread in the LN prologues
+    constexpr int S64 = 64;
+    const uint32_t nvec = D >> 3;
+    const float eps = S.ln_eps;
+    // rows of a wave in the KS == 1 stages: a contiguous, even-sized block
+    auto wave_rows = [&](uint32_t nrows, uint32_t& b, uint32_t& e) {
+        const uint32_t q = (((nrows + 3u) >> 2) + 1u) & ~1u;
+        b = min(wave * q, nrows);
+        e = min(b + q, nrows);
+    };
+    // K2 thread roles (head_kernel): (row, part) for the LoRA dots, (i, g4) for the state
+    const uint32_t row = tid >> 2, prt = tid & 3u, ci64 = tid & 63u, g4 = tid >> 6;
+    const uint32_t c0 = is_head ? head * S64 : 0u, ch = c0 + row;
+    float vfirst_keep = 0.0f;
+    if (is_head && S.layer_begin > 0) vfirst_keep = (float)((const f16*)A.v_first)[ch];
+
+    for (uint32_t l = S.layer_begin; l < S.layer_end; ++l) {
+        const EngLayer& L = A.layers[l];
+        float* lst = layer_state(l);
+        const bool layer0 = l == 0;
+
+        // ---- requests that depend on nothing: LN1 operands
+        f16x8 wv[VPT], bv[VPT], mv[VPT];
+        f32x4 pv[VPT][2];
+        {
+            const f16* mixp = (const f16*)L.mix[j1 < ENG_K1_JOBS ? S.k1[j1].mix : 0u];
+#pragma unroll
+            for (int v = 0; v < VPT; ++v) {
+                const uint32_t i = min(tid + 256u * v, nvec - 1);
+                wv[v] = *(const f16x8*)((const f16*)L.ln1_w + i * 8);
+                bv[v] = *(const f16x8*)((const f16*)L.ln1_b + i * 8);
+                mv[v] = *(const f16x8*)(mixp + i * 8);
+                pv[v][0] = *(const f32x4*)(lst + i * 8);
+                pv[v][1] = *(const f32x4*)(lst + i * 8 + 4);
+            }
+        }
+        // ================================================ K1
+        ENG_BAR();                                          // x in xraw0, K1 weights in their slot
+        if (*abort_flag) break;
+        ENG_STAMP(l, 1);
+        eng_ln_mix<VPT>(xraw0, xs, lnbuf, red, D, eps, wv, bv, mv, pv, tid, lane, wave);
+        ENG_STAMP(l, 2);
+        if (k1_active(l)) {
+            const EngJob& J = S.k1[j1];
+            uint32_t rb, re;
+            wave_rows(k1_rows, rb, re);
+            const EngFin fin{J.act, L.scale[j1], nullptr, 1.0f};
+            const lds_u8* slot = smem + S.lds_slot1;
+            if (J.f16) {
+                const uint32_t gb = S.g_k1 + J.gbase;
+                eng_rows<WRK_MAT_F16, false, 4 * XD, 2>(slot, k1_rb, D, xs, k1_row0, rb, re, fin, A.gran, eng_tag(l, 0),
+                                                     [&](uint32_t r) { return gb + (r >> 1); }, (f16*)nullptr, lane);
+            } else {
+                const uint32_t gb = S.g_k1 + S.g_aux + J.gbase * 32u;
+                eng_rows<QK, R16, XD, 4>(slot, k1_rb, D, xs, k1_row0, rb, re, fin, A.gran, eng_tag(l, 0),
+                                      [&](uint32_t r) { return gb + (r >> 6) * 96u + ((r & 63u) >> 1); }, (f16*)nullptr, lane);
+            }
+        }
+        ENG_STAMP(l, 3);
+        // (heads) requests of K2 that depend on nothing: LoRA up-projection rows, per-channel vectors, the state -- in flight across the
+        // K1 -> K2 hand-off
+        f16x8 lw[4], la[4], lv[4], lg[8];
+        float Sreg[16];
+        f16 h_w0 = 0, h_a0 = 0, h_kk = 0, h_ka = 0, h_v0 = 0, h_gnw = 0, h_gnb = 0, h_rk = 0;
+        float* st = lst + (size_t)D + c0 + ci64;            // S[j][c0 + i] at st[j * D]
+        if (is_head) {
+            const f16* w2r = (const f16*)(L.w2 + (size_t)ch * S.rb_w2);
+            const f16* a2r = (const f16*)(L.a2 + (size_t)ch * S.rb_a2);
+            const f16* g2r = (const f16*)(L.g2 + (size_t)ch * S.rb_g2);
+            const f16* v2r = layer0 ? w2r : (const f16*)(L.v2 + (size_t)ch * S.rb_v2);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                lw[n] = *(const f16x8*)(w2r + min(prt * 8 + 32 * n, S.rw - 8));
+                la[n] = *(const f16x8*)(a2r + min(prt * 8 + 32 * n, S.ra - 8));
+                lv[n] = *(const f16x8*)(v2r + min(prt * 8 + 32 * n, (layer0 ? S.rw : S.rv) - 8));
+            }
+#pragma unroll
+            for (int n = 0; n < 8; ++n) lg[n] = *(const f16x8*)(g2r + min(prt * 8 + 32 * n, S.rg - 8));
+            h_w0 = ((const f16*)L.w0)[ch]; h_a0 = ((const f16*)L.a0)[ch]; h_kk = ((const f16*)L.k_k)[ch]; h_ka = ((const f16*)L.k_a)[ch];
+            h_v0 = ((const f16*)(layer0 ? L.w0 : L.v0))[ch];
+            h_gnw = ((const f16*)L.gn_w)[c0 + ci64]; h_gnb = ((const f16*)L.gn_b)[c0 + ci64]; h_rk = ((const f16*)L.r_k)[c0 + ci64];
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) Sreg[jj] = st[(size_t)(g4 * 16 + jj) * D];
+        }
+
+        ENG_BAR();                                          // K1 done: slot, xs free
+
+        // ================================================ K2 (one workgroup per head): head_kernel's arithmetic
+        if (is_head) {
+            ENG_LDS float* sh_r = k2f; ENG_LDS float* sh_w = k2f + 64; ENG_LDS float* sh_k = k2f + 128; ENG_LDS float* sh_v = k2f + 192;
+            ENG_LDS float* sh_a = k2f + 256; ENG_LDS float* sh_b = k2f + 320; ENG_LDS float* sh_g = k2f + 384; ENG_LDS float* sh_kk = k2f + 448;
+            ENG_LDS float* sh_red = k2f + 512;              // [4][64]
+            ENG_BAR();                                      // LoRA intermediates and r, k, v of this head in auxbuf
+            if (*abort_flag) break;
+            ENG_STAMP(l, 4);
+            const ENG_LDS f16* aw = auxbuf, *aa = auxbuf + S.rw, *ag = auxbuf + S.rw + S.ra, *av = auxbuf + S.rw + S.ra + S.rg;
+            const ENG_LDS f16* hr = auxbuf + naux, *hk = hr + 64, *hv = hr + 128;
+            const float w0 = (float)h_w0, a0 = (float)h_a0, kkw = (float)h_kk, kaw = (float)h_ka;
+            const float kraw = (float)hk[row], rraw = (float)hr[row];
+            float v = (float)hv[row];
+            const float v0w = layer0 ? 0.0f : (float)h_v0, vfirst = layer0 ? 0.0f : vfirst_keep;
+            const float gnw = (float)h_gnw, gnb = (float)h_gnb, rkw = (float)h_rk;
+            const float shift = (float)lnbuf[c0 + ci64];
+            {
+                const float dw = eng_lora_dot<4>(lw, aw, S.rw, prt);
+                const float da = eng_lora_dot<4>(la, aa, S.ra, prt);
+                const float dg = eng_lora_dot<8>(lg, ag, S.rg, prt);
+                float dv = 0.0f;
+                if (!layer0) dv = eng_lora_dot<4>(lv, av, S.rv, prt);
+                if (layer0) vfirst_keep = v;                                                  // blit(att_v, att_v0): an f16 value
+                if (prt == 0) {
+                    const float w = r16(w0 + r16(dw));
+                    const float a = r16(act_sigmoid(a0 + r16(da)));
+                    const float g = r16(dg);
+                    if (layer0) ((f16*)A.v_first)[ch] = (f16)v;
+                    else {
+                        const float vv = r16(act_sigmoid(v0w + r16(dv)));
+                        v = r16(wgsl_mix(v, vfirst, vv));
+                    }
+                    sh_w[row] = __expf(-0.606531f * act_sigmoid(w));
+                    sh_a[row] = a;
+                    sh_g[row] = g;
+                    sh_v[row] = v;
+                    sh_r[row] = rraw;
+                    sh_kk[row] = r16(kkw * kraw);
+                    sh_k[row] = r16(kraw * (1.0f + (a - 1.0f) * kaw));
+                }
+            }
+            if (g4 == 1) lst[c0 + ci64] = shift;                                               // att shift state <- LN1(x)
+            ENG_BAR();
+            if (g4 == 0) {
+                const float kkv = sh_kk[ci64];
+                const float nrm = 1.0f / sqrtf(wave_sum(kkv * kkv) + S.l2_eps);
+                const float kkn = r16(kkv * nrm);
+                const float a = sh_a[ci64];
+                sh_a[ci64] = -kkn;
+                sh_b[ci64] = kkn * a;
+            }
+            ENG_BAR();
+            float sa = 0.0f;
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) sa = __builtin_fmaf(Sreg[jj], sh_a[g4 * 16 + jj], sa);
+            sh_red[g4 * 64 + ci64] = sa;
+            ENG_BAR();
+            sa = (sh_red[ci64] + sh_red[64 + ci64]) + (sh_red[128 + ci64] + sh_red[192 + ci64]);
+            const float vv = sh_v[ci64];
+            float y = 0.0f;
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) {
+                const int j = g4 * 16 + jj;
+                const float s = Sreg[jj] * sh_w[j] + sh_k[j] * vv + sa * sh_b[j];
+                st[(size_t)j * D] = s;
+                y = __builtin_fmaf(sh_r[j], s, y);
+            }
+            ENG_BAR();
+            sh_red[g4 * 64 + ci64] = y;
+            ENG_BAR();
+            if (g4 == 0) {
+                y = r16((sh_red[ci64] + sh_red[64 + ci64]) + (sh_red[128 + ci64] + sh_red[192 + ci64]));
+                const float mean = wave_sum(y) * (1.0f / S64);
+                const float dl = y - mean;
+                const float var = wave_sum(dl * dl) * (1.0f / S64) + S.gn_eps;
+                float o = r16(__builtin_fmaf(dl * (1.0f / sqrtf(var)), gnw, gnb));
+                const float xx = wave_sum(rkw * sh_k[ci64] * sh_r[ci64]);
+                o = r16(o + xx * vv);
+                o = sh_g[ci64] * o;
+                const float o_next = __shfl_down(o, 1, WAVE);
+                if ((ci64 & 1u) == 0) eng_store_granule(A.gran + S.g_o + ((c0 + ci64) >> 1), eng_tag(l, 1), pack_h2(o, o_next));
+            }
+            ENG_STAMP(l, 5);
+            ENG_BAR();                                      // K2 done
+        }
+
+        // ================================================ K3: x1 = x + W_o . o
+        ENG_BAR();                                          // o in xs, W_o rows in their slot
+        if (*abort_flag) break;
+        ENG_STAMP(l, 6);
+        {
+            uint32_t rb, re;
+            wave_rows(k3_rows, rb, re);
+            const EngFin fin{WRK_ACT_NONE, L.scale_o, xraw0, 1.0f};
+            const uint32_t gb = S.g_x1;
+            eng_rows<QK, R16, XD, 4>(smem + S.lds_slot3, S.rb_d, D, xs, k3_row0, rb, re, fin, A.gran, eng_tag(l, 2), [&](uint32_t r) { return gb + (r >> 1); },
+                                  (f16*)nullptr, lane);
+        }
+        // requests of K5's prologue (the ffn shift state was last written by the previous token)
+        {
+            float* rowf = lst + (size_t)(srows - 1) * D;
+#pragma unroll
+            for (int v = 0; v < VPT; ++v) {
+                const uint32_t i = min(tid + 256u * v, nvec - 1);
+                wv[v] = *(const f16x8*)((const f16*)L.ln2_w + i * 8);
+                bv[v] = *(const f16x8*)((const f16*)L.ln2_b + i * 8);
+                mv[v] = *(const f16x8*)((const f16*)L.ffn_x_k + i * 8);
+                pv[v][0] = *(const f32x4*)(rowf + i * 8);
+                pv[v][1] = *(const f32x4*)(rowf + i * 8 + 4);
+            }
+        }
+        ENG_STAMP(l, 7);
+        ENG_BAR();                                          // K3 done
+
+        // ================================================ K5: k = relu(ffn_key . mix(LN2(x1)))^2
+        ENG_BAR();                                          // x1 in xraw1, ffn key rows in their slot
+        if (*abort_flag) break;
+        ENG_STAMP(l, 8);
+        eng_ln_mix<VPT>(xraw1, xs, lnbuf, red, D, eps, wv, bv, mv, pv, tid, lane, wave);
+        {
+            uint32_t rb, re;
+            wave_rows(k5_rows, rb, re);
+            const EngFin fin{WRK_ACT_SQUARED_RELU, L.scale_fk, nullptr, 1.0f};
+            const uint32_t gb = S.g_k;
+            eng_rows<QK, R16, XD, 4>(smem + S.lds_slot5, S.rb_d, D, xs, k5_row0, rb, re, fin, A.gran, eng_tag(l, 3), [&](uint32_t r) { return gb + (r >> 1); },
+                                  (f16*)nullptr, lane);
+        }
+        ENG_STAMP(l, 9);
+        ENG_BAR();                                          // K5 done
+
+        // ================================================ K6: x = x1 + ffn_value . k   (K over the four waves)
+        ENG_BAR();                                          // k in xs (F elements), ffn value rows in their slot
+        if (*abort_flag) break;
+        ENG_STAMP(l, 10);
+        {
+            const uint32_t kpad = (F + 15u) & ~15u;
+            const uint32_t nch = num_chunks<QK>(F, kpad);
+            const uint32_t cbase = lane + 64u * wave;
+            XRegs x[1][XD];
+#pragma unroll
+            for (int ci = 0; ci < XD; ++ci) {
+                const uint32_t c = cbase + 256u * ci;
+                x[0][ci] = lds_x<QK>(xs, min(c, nch - 1));
+                if (c >= nch) {
+                    const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                    x[0][ci].v[0] = x[0][ci].v[1] = x[0][ci].v[2] = x[0][ci].v[3] = z;
+                }
+                x_sums<QK>(x[0][ci]);
+            }
+            const lds_u8* slot = smem + S.lds_slot6;
+            for (uint32_t ri = 0; ri < k6_rows; ri += 4) {
+                Raw raw[4][XD];
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb) {
+                    const lds_u8* rowp = slot + (size_t)min(ri + rb, k6_rows - 1) * S.rb_f;
+#pragma unroll
+                    for (int ci = 0; ci < XD; ++ci) raw[rb][ci] = lds_raw<QK>(rowp, F, min(cbase + 256u * ci, nch - 1));
+                }
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb) {
+                    float acc[1] = {0.0f};
+#pragma unroll
+                    for (int ci = 0; ci < XD; ++ci) dot_raw_tokens<QK, R16, 1, XD>(raw[rb][ci], min(cbase + 256u * ci, nch - 1), x, ci, acc);
+                    const float pvs = wave_sum(acc[0]);
+                    if (lane == 0 && ri + rb < k6_rows) part[(ri + rb) * 4 + wave] = pvs;
+                }
+            }
+        }
+        ENG_BAR();
+        if (tid < 64) {                                     // one wave finishes the (at most 32) rows
+            const bool valid = tid < k6_rows;
+            const uint32_t r = k6_row0 + min(tid, k6_rows ? k6_rows - 1 : 0u);
+            float o = 0.0f;
+            if (k6_rows) {
+                const uint32_t p = min(tid, k6_rows - 1);
+                o = ((part[p * 4] + part[p * 4 + 1]) + (part[p * 4 + 2] + part[p * 4 + 3])) * L.scale_fv;
+                o = r16(o) + (float)xraw1[r];
+                if ((l + 1) % S.rescale == 0) o = r16(o) * 0.5f;                              // affine(x, 0.5) after the layer
+            }
+            const float o_next = __shfl_down(o, 1, WAVE);
+            if (valid) {
+                lst[(size_t)(srows - 1) * D + r] = (float)lnbuf[r];                           // ffn shift state <- LN2(x1)
+                if ((tid & 1u) == 0) eng_store_granule(A.gran + S.g_x + (r >> 1), eng_tag(l, 4), pack_h2(o, o_next));
+                if (l + 1 == S.layer_end) ((f16*)A.x_out)[r] = (f16)o;
+            }
+        }
+        ENG_STAMP(l, 11);
+        ENG_BAR();                                          // K6 done
+    }
+#undef ENG_STAMP
+}
+
+}  // namespace wrk
+
+// ------------------------------------------------------------------ host
+struct wrk_v7_engine {
+    wrk_v7_model* m = nullptr;
+    wrk::EngShape S{};
+    wrk::EngLayer* layers = nullptr;        // device [L]
+    uint32_t* wg_head = nullptr;            // device [nwg]
+    unsigned long long* gran = nullptr;     // device
+    uint32_t* fail = nullptr;               // device (pinned readable through memcpy)
+    unsigned long long* stamps = nullptr;   // device, WRK_TIMING=1
+    bool r16 = false;
+    int xd = 1;
+    uint32_t quant = 0;
+};
+
+static uint32_t up(uint32_t v, uint32_t a) { return (v + a - 1) / a * a; }
+
+int32_t wrk_v7_engine_create(wrk_v7_model* m, wrk_v7_engine** out) {
+    using namespace wrk;
+    wrk_ctx* ctx = m->ctx;
+    *out = nullptr;
+    const auto& d = m->d;
+    const uint32_t D = d.num_emb, F = d.num_hidden, H = d.num_head, NWG = (uint32_t)ctx->num_cu;
+    auto no = [&](const char* why) { return wrk_fail(ctx, WRK_E_UNSUPPORTED, "decode engine: %s", why); };
+    if (m->act_dtype != WRK_F16) return no("f32 frames");
+    if (H == 0 || D != H * 64 || D % 256 || D > 4096 || F % 1024 || F != 4 * D) return no("shape");
+    if (d.lora_w % 8 || d.lora_a % 8 || d.lora_g % 8 || d.lora_v % 8 || d.lora_w < 8 || d.lora_a < 8 || d.lora_g < 8 || d.lora_v < 8 ||
+        d.lora_w > 128 || d.lora_a > 128 || d.lora_v > 128 || d.lora_g > 256 || ((d.lora_w + d.lora_a + d.lora_g + d.lora_v) % 16))
+        return no("LoRA ranks");
+    if (NWG < H || NWG < 64) return no("too few compute units");
+    // every big matrix of one quantised kind (Q4_K: the headline configuration), LoRA matrices F16, one rounding mode
+    uint32_t quant = 0xffffffffu, flags = 0xffffffffu;
+    for (size_t li = 0; li < m->layers.size(); ++li) {
+        const auto& L = m->layers[li];
+        const wrk_matrix* big[] = {L.w_r, L.w_k, L.w_v, L.w_o, L.ffn_w_k, L.ffn_w_v};
+        for (const wrk_matrix* q : big) {
+            if (quant == 0xffffffffu) { quant = q->kind; flags = q->flags; }
+            if (q->kind != quant || q->flags != flags) return no("mixed matrix kinds");
+        }
+        const wrk_matrix* lo[] = {L.w1, L.a1, L.g1, li ? L.v1 : L.a1, L.w2, L.a2, L.g2, li ? L.v2 : L.a2};
+        for (const wrk_matrix* q : lo)
+            if (!q || q->kind != WRK_MAT_F16) return no("LoRA matrices must be F16");
+        if (L.w_r->k != D || L.w_r->m != D || L.ffn_w_k->m != F || L.ffn_w_v->k != F || L.w1->m != d.lora_w || L.a1->m != d.lora_a ||
+            L.g1->m != d.lora_g || (li && L.v1->m != d.lora_v))
+            return no("matrix shapes");
+    }
+    if (quant != WRK_MAT_Q4_K) return no("only Q4_K matrices so far");
+    if (m->layers.empty()) return no("no layers");
+
+    wrk_v7_engine* e = new wrk_v7_engine();
+    e->m = m;
+    e->quant = quant;
+    e->r16 = (flags & WRK_MATRIX_ROUND_F16) != 0;
+    e->xd = D <= 2048 ? 1 : 2;
+    EngShape& S = e->S;
+    S.D = D; S.F = F; S.H = H; S.nwg = NWG;
+    S.rw = d.lora_w; S.ra = d.lora_a; S.rg = d.lora_g; S.rv = d.lora_v;
+    const auto& L0 = m->layers[0];
+    const auto& L1 = m->layers[m->layers.size() > 1 ? 1 : 0];
+    S.rb_d = (uint32_t)L0.w_r->row_bytes; S.rb_f = (uint32_t)L0.ffn_w_v->row_bytes;
+    S.rb_w2 = (uint32_t)L0.w2->row_bytes; S.rb_a2 = (uint32_t)L0.a2->row_bytes; S.rb_g2 = (uint32_t)L0.g2->row_bytes;
+    S.rb_v2 = (uint32_t)(m->layers.size() > 1 ? L1.v2->row_bytes : L0.a2->row_bytes);
+    for (const auto& L : m->layers) {
+        if (L.w_r->row_bytes != S.rb_d || L.w_k->row_bytes != S.rb_d || L.w_v->row_bytes != S.rb_d || L.w_o->row_bytes != S.rb_d ||
+            L.ffn_w_k->row_bytes != S.rb_d || L.ffn_w_v->row_bytes != S.rb_f || L.w2->row_bytes != S.rb_w2 || L.a2->row_bytes != S.rb_a2 ||
+            L.g2->row_bytes != S.rb_g2) { delete e; return no("row strides differ between layers"); }
+    }
+    // ---- K1: workgroups to matrices in proportion to bytes; rows per workgroup a multiple of 8 (4 waves x row pairs)
+    const uint32_t rb_l = (uint32_t)L0.w1->row_bytes;
+    struct { uint32_t rows, rb, f16, act, mix, headed, gbase; } jd[ENG_K1_JOBS] = {
+        {D, S.rb_d, 0, WRK_ACT_NONE, 0, 1, 0}, {D, S.rb_d, 0, WRK_ACT_NONE, 2, 1, 1}, {D, S.rb_d, 0, WRK_ACT_NONE, 3, 1, 2},
+        {S.rw, rb_l, 1, WRK_ACT_TANH, 1, 0, 0}, {S.ra, rb_l, 1, WRK_ACT_NONE, 4, 0, S.rw / 2}, {S.rg, rb_l, 1, WRK_ACT_SIGMOID, 5, 0, (S.rw + S.ra) / 2},
+        {S.rv, rb_l, 1, WRK_ACT_NONE, 3, 0, (S.rw + S.ra + S.rg) / 2}};
+    double total = 0;
+    for (auto& j : jd) total += (double)j.rows * j.rb;
+    uint32_t slot1 = 0;
+    bool placed = false;
+    for (double target = total / NWG; target < total; target *= 1.03) {
+        uint32_t used = 0, worst = 0;
+        uint32_t rpw[ENG_K1_JOBS], nw[ENG_K1_JOBS];
+        for (int j = 0; j < ENG_K1_JOBS; ++j) {
+            uint32_t r = (uint32_t)(target / jd[j].rb);
+            r = std::max(8u, r / 8 * 8);
+            rpw[j] = r;
+            nw[j] = (jd[j].rows + r - 1) / r;
+            used += nw[j];
+            worst = std::max(worst, std::min(r, jd[j].rows) * jd[j].rb);
+        }
+        if (used > NWG) continue;
+        uint32_t w0 = 0;
+        for (int j = 0; j < ENG_K1_JOBS; ++j) {
+            S.k1[j] = EngJob{jd[j].rows, jd[j].rb, jd[j].f16, jd[j].act, jd[j].mix, w0, nw[j], rpw[j], jd[j].gbase, jd[j].headed};
+            w0 += nw[j];
+        }
+        slot1 = worst;
+        placed = true;
+        break;
+    }
+    if (!placed) { delete e; return no("K1 partition"); }
+    S.k3_rpw = std::max(8u, up((D + NWG - 1) / NWG, 8));
+    S.k5_rpw = std::max(8u, up((F + NWG - 1) / NWG, 8));
+    S.k6_rpw = std::max(2u, up((D + NWG - 1) / NWG, 2));
+    if (S.k6_rpw > 32) { delete e; return no("ffn value rows per workgroup"); }
+    // ---- LDS
+    uint32_t off = 0;
+    auto take = [&](uint32_t bytes) { const uint32_t o = off; off += up(bytes, 1024); return o; };
+    S.lds_slot1 = take(slot1);
+    S.lds_slot5 = take(S.k5_rpw * S.rb_d);
+    S.lds_slot6 = take(S.k6_rpw * S.rb_f);
+    S.lds_slot3 = take(S.k3_rpw * S.rb_d);
+    S.lds_xraw0 = take(D * 2);
+    S.lds_xraw1 = take(D * 2);
+    const uint32_t naux = S.rw + S.ra + S.rg + S.rv;
+    S.lds_xs = take(std::max(F * 2, D * 2 + up((naux + 192) * 2, 16) + 768 * 4));      // the ffn vector; K2's scratch lives behind its first D elements
+    S.lds_ln = take(D * 2);
+    S.lds_misc = take(1024);
+    S.lds_total = off;
+    int lds_max = 0;
+    hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, ctx->device);
+    if (lds_max < 160 * 1024) lds_max = 160 * 1024;      // gfx950: 160 KiB per workgroup (the attribute reports the 64 KiB default limit on some stacks)
+    if (S.lds_total > (uint32_t)lds_max) { delete e; return no("weights of a layer do not fit the LDS"); }
+    // ---- granules
+    S.g_aux = naux / 2;
+    uint32_t g = 0;
+    auto gtake = [&](uint32_t n) { const uint32_t o = g; g += up(n, 128); return o; };
+    S.g_x = gtake(D / 2);
+    S.g_k1 = gtake(S.g_aux + H * 96);
+    S.g_o = gtake(D / 2);
+    S.g_x1 = gtake(D / 2);
+    S.g_k = gtake(F / 2);
+    S.g_total = g;
+    S.ln_eps = 1.0e-5f; S.gn_eps = 64.0e-5f; S.l2_eps = 1.0e-12f;
+    S.rescale = d.rescale ? d.rescale : 0xffffffffu;
+    S.state_rows = 64 + 2;
+
+    auto fail_alloc = [&](hipError_t er) { wrk_v7_engine_destroy(e); return wrk_fail(ctx, WRK_E_OOM, "decode engine: %s", hipGetErrorString(er)); };
+    hipError_t er;
+    std::vector<EngLayer> hl(m->layers.size());
+    for (size_t li = 0; li < m->layers.size(); ++li) {
+        const auto& L = m->layers[li];
+        EngLayer& o = hl[li];
+        o.w_r = L.w_r->data; o.w_k = L.w_k->data; o.w_v = L.w_v->data; o.w1 = L.w1->data; o.a1 = L.a1->data; o.g1 = L.g1->data;
+        o.v1 = li ? L.v1->data : L.a1->data;
+        o.w2 = L.w2->data; o.a2 = L.a2->data; o.g2 = L.g2->data; o.v2 = li ? L.v2->data : L.a2->data;
+        o.w_o = L.w_o->data; o.ffn_k = L.ffn_w_k->data; o.ffn_v = L.ffn_w_v->data;
+        o.ln1_w = L.ln1_w->ptr; o.ln1_b = L.ln1_b->ptr; o.ln2_w = L.ln2_w->ptr; o.ln2_b = L.ln2_b->ptr;
+        const wrk_buf* mx[6] = {L.x_r, L.x_w, L.x_k, L.x_v, L.x_a, L.x_g};
+        for (int i = 0; i < 6; ++i) o.mix[i] = mx[i]->ptr;
+        o.w0 = L.w0->ptr; o.a0 = L.a0->ptr; o.v0 = li ? L.v0->ptr : L.w0->ptr; o.r_k = L.r_k->ptr; o.k_k = L.k_k->ptr; o.k_a = L.k_a->ptr;
+        o.gn_w = L.gn_w->ptr; o.gn_b = L.gn_b->ptr; o.ffn_x_k = L.ffn_x_k->ptr;
+        const wrk_matrix* k1m[ENG_K1_JOBS] = {L.w_r, L.w_k, L.w_v, L.w1, L.a1, L.g1, li ? L.v1 : L.a1};
+        for (int j = 0; j < ENG_K1_JOBS; ++j) o.scale[j] = k1m[j]->out_scale;
+        o.scale_o = L.w_o->out_scale; o.scale_fk = L.ffn_w_k->out_scale; o.scale_fv = L.ffn_w_v->out_scale;
+    }
+    if ((er = hipMalloc((void**)&e->layers, hl.size() * sizeof(EngLayer))) != hipSuccess) return fail_alloc(er);
+    if ((er = hipMemcpy(e->layers, hl.data(), hl.size() * sizeof(EngLayer), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(er);
+    std::vector<uint32_t> hh(NWG, ENG_NO_HEAD);
+    for (uint32_t h = 0; h < H; ++h) hh[(size_t)h * NWG / H] = h;
+    if ((er = hipMalloc((void**)&e->wg_head, NWG * 4)) != hipSuccess) return fail_alloc(er);
+    if ((er = hipMemcpy(e->wg_head, hh.data(), NWG * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(er);
+    if ((er = hipMalloc((void**)&e->gran, (size_t)S.g_total * 8)) != hipSuccess) return fail_alloc(er);
+    if ((er = hipMalloc((void**)&e->fail, 256)) != hipSuccess) return fail_alloc(er);
+    if ((er = hipMemset(e->fail, 0, 256)) != hipSuccess) return fail_alloc(er);
+    const char* tm = getenv("WRK_TIMING");
+    if (tm && tm[0] == '1') {
+        const size_t n = (size_t)NWG * 6 * ENG_STAMPS * 8;
+        if ((er = hipMalloc((void**)&e->stamps, n)) != hipSuccess) return fail_alloc(er);
+        hipMemset(e->stamps, 0, n);
+    }
+    // dynamic LDS above 64 KiB needs the attribute, per device
+    const void* fns[] = {(const void*)v7_engine_kernel<1, false, WRK_MAT_Q4_K>, (const void*)v7_engine_kernel<1, true, WRK_MAT_Q4_K>,
+                         (const void*)v7_engine_kernel<2, false, WRK_MAT_Q4_K>, (const void*)v7_engine_kernel<2, true, WRK_MAT_Q4_K>};
+    for (const void* f : fns)
+        if ((er = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_total)) != hipSuccess) {
+            wrk_v7_engine_destroy(e);
+            return wrk_fail(ctx, WRK_E_UNSUPPORTED, "decode engine: %u bytes of LDS refused (%s)", S.lds_total, hipGetErrorString(er));
+        }
+    // one workgroup per CU, all resident
+    int per_cu = 0;
+    er = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fns[(e->xd == 2 ? 2 : 0) + (e->r16 ? 1 : 0)], (int)ENG_THREADS, S.lds_total);
+    if (er != hipSuccess || per_cu < 1) { wrk_v7_engine_destroy(e); return no("the kernel is not resident with this much LDS"); }
+    *out = e;
+    return WRK_OK;
+}
+
+void wrk_v7_engine_destroy(wrk_v7_engine* e) {
+    if (!e) return;
+    if (e->layers) hipFree(e->layers);
+    if (e->wg_head) hipFree(e->wg_head);
+    if (e->gran) hipFree(e->gran);
+    if (e->fail) hipFree(e->fail);
+    if (e->stamps) hipFree(e->stamps);
+    delete e;
+}
+
+int32_t wrk_v7_engine_enqueue(wrk_v7_engine* e, hipStream_t q, wrk_v7_state* st, uint32_t batch, uint32_t l0, uint32_t l1, const void* x_in, void* x_out,
+                              void* v_first) {
+    using namespace wrk;
+    wrk_ctx* ctx = e->m->ctx;
+    EngArgs A{};
+    A.S = e->S;
+    A.S.layer_begin = l0; A.S.layer_end = l1; A.S.batch = batch;
+    A.layers = e->layers; A.gran = e->gran; A.x_in = x_in; A.x_out = x_out; A.v_first = v_first;
+    A.state = st->data; A.num_batch = st->num_batch; A.fail = e->fail; A.stamps = e->stamps; A.stamp_layer = std::min(5u, l1 - 1);
+    // every polled word zeroed before every launch (a memset node, replayed first): tags are > 0 and unique within a launch
+    WRK_HIP(ctx, hipMemsetAsync(e->gran, 0, (size_t)e->S.g_total * 8, q));
+    const dim3 grid(e->S.nwg), block(ENG_THREADS);
+    const uint32_t lds = e->S.lds_total;
+    if (e->xd == 1) {
+        if (e->r16) v7_engine_kernel<1, true, WRK_MAT_Q4_K><<<grid, block, lds, q>>>(A, e->wg_head);
+        else v7_engine_kernel<1, false, WRK_MAT_Q4_K><<<grid, block, lds, q>>>(A, e->wg_head);
+    } else {
+        if (e->r16) v7_engine_kernel<2, true, WRK_MAT_Q4_K><<<grid, block, lds, q>>>(A, e->wg_head);
+        else v7_engine_kernel<2, false, WRK_MAT_Q4_K><<<grid, block, lds, q>>>(A, e->wg_head);
+    }
+    WRK_LAUNCH_CHECK(ctx);
+    return WRK_OK;
+}
+
+int32_t wrk_v7_engine_check(wrk_v7_engine* e) {
+    if (!e) return WRK_OK;
+    wrk_ctx* ctx = e->m->ctx;
+    uint32_t f = 0;
+    WRK_HIP(ctx, hipMemcpy(&f, e->fail, 4, hipMemcpyDeviceToHost));
+    if (f) {
+        hipMemset(e->fail, 0, 4);
+        return wrk_fail(ctx, WRK_E_HIP, "decode engine: a hand-off wait gave up (stage mask 0x%x): workgroups not co-resident or a producer died", f);
+    }
+    return WRK_OK;
+}
+
+void wrk_v7_engine_report(wrk_v7_engine* e) {
+    using namespace wrk;
+    if (!e || !e->stamps) return;
+    const uint32_t NWG = e->S.nwg;
+    std::vector<unsigned long long> h((size_t)NWG * 6 * ENG_STAMPS);
+    if (hipMemcpy(h.data(), e->stamps, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
+    unsigned long long t0 = ~0ull;
+    for (auto v : h) if (v && v < t0) t0 = v;
+    auto col = [&](uint32_t wave, uint32_t k, const char* label) {
+        std::vector<double> v;
+        for (uint32_t w = 0; w < NWG; ++w) { const auto x = h[((size_t)w * 6 + wave) * ENG_STAMPS + k]; if (x) v.push_back((double)(x - t0) * 0.01); }
+        if (v.empty()) return;
+        std::sort(v.begin(), v.end());
+        fprintf(stderr, "  %-58s %4zu WGs  first %7.2f  median %7.2f  last %7.2f us\n", label, v.size(), v.front(), v[v.size() / 2], v.back());
+    };
+    fprintf(stderr, "[WRK_TIMING] decode engine, one layer of the last token; us since the layer's first stamp\n");
+    col(4, 0, "gather: layer input complete");
+    col(0, 1, "K1 start (input + weights in LDS)");
+    col(0, 2, "K1 LN + shift done");
+    col(0, 3, "K1 rows published");
+    col(4, 1, "gather (heads): K1 outputs complete");
+    col(0, 4, "K2 start");
+    col(0, 5, "K2 published");
+    col(4, 2, "gather: head outputs complete");
+    col(0, 6, "K3 start");
+    col(0, 7, "K3 published");
+    col(4, 3, "gather: x1 complete");
+    col(0, 8, "K5 start");
+    col(0, 9, "K5 published");
+    col(4, 4, "gather: ffn vector complete");
+    col(0, 10, "K6 start");
+    col(0, 11, "K6 published");
+    col(5, 0, "loader: K1 slot free, next layer's fill issued");
+}

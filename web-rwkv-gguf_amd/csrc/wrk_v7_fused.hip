@@ -18,6 +18,8 @@
 // Runtime<f16> buffers) would store it, so mode 0 and mode 1 agree to f32 summation order.
 #include "wrk_device.h"
 #include "wrk_v7.h"
+#include "wrk_v7_engine.h"
+#include "wrk_lora_dev.h"
 
 namespace wrk {
 
@@ -149,42 +151,6 @@ struct HeadParams {
     uint32_t batch1;                            // batch id + 1 when the host knows it (single-sequence decode), else 0: read the cursor
     unsigned long long* dbg;
 };
-
-// dot of a row slice of an f16 [D][rank] matrix with the token's f16 LoRA intermediate; 4 lanes share a
-// row (lane `part` takes columns part*8 + 32*n ..+8).  Loads and arithmetic are separate calls so the kernel
-// can put EVERY load of the launch in flight before the first wait (loads return in issue order).
-template <int MAXCH>
-struct LoraRegs { f16x8 w[MAXCH], x[MAXCH]; };
-
-template <int MAXCH>
-__device__ __forceinline__ void lora_load(LoraRegs<MAXCH>& r, const f16* __restrict__ wrow, const f16* __restrict__ aux, uint32_t rank, uint32_t part) {
-#pragma unroll
-    for (int n = 0; n < MAXCH; ++n) {
-        // unconditional (column clamped; lora_dot masks the chunks beyond the rank): predicated loads make the compiler lose count of
-        // what is in flight and wait vmcnt(0) between dependent groups
-        const uint32_t c = min(part * 8 + 32 * n, rank - 8);
-        r.w[n] = *(const f16x8*)(wrow + c);
-        r.x[n] = *(const f16x8*)(aux + c);
-    }
-}
-
-template <int MAXCH>
-__device__ __forceinline__ float lora_dot(const LoraRegs<MAXCH>& r, uint32_t rank, uint32_t part) {
-    float acc = 0.0f;
-#pragma unroll
-    for (int n = 0; n < MAXCH; ++n) {
-        const uint32_t c = part * 8 + 32 * n;
-        if (c < rank) {
-            acc = __builtin_amdgcn_fdot2(__builtin_shufflevector(r.w[n], r.w[n], 0, 1), __builtin_shufflevector(r.x[n], r.x[n], 0, 1), acc, false);
-            acc = __builtin_amdgcn_fdot2(__builtin_shufflevector(r.w[n], r.w[n], 2, 3), __builtin_shufflevector(r.x[n], r.x[n], 2, 3), acc, false);
-            acc = __builtin_amdgcn_fdot2(__builtin_shufflevector(r.w[n], r.w[n], 4, 5), __builtin_shufflevector(r.x[n], r.x[n], 4, 5), acc, false);
-            acc = __builtin_amdgcn_fdot2(__builtin_shufflevector(r.w[n], r.w[n], 6, 7), __builtin_shufflevector(r.x[n], r.x[n], 6, 7), acc, false);
-        }
-    }
-    acc += dpp_f32<0xB1>(acc);      // lane ^ 1, lane ^ 2 inside the quad by DPP (ds_bpermute = an LDS round trip each on the head kernels' critical path)
-    acc += dpp_f32<0x4E>(acc);
-    return acc;
-}
 
 template <int GCH>     // 32-column chunks of the gate LoRA held per lane group: rank_g <= 32 * GCH
 __global__ void __launch_bounds__(256) head_kernel(const HeadParams P) {
@@ -598,7 +564,17 @@ int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_
         P.d = D; P.nmix = 0; P.ln_out = (f16*)s.x;
         LN(P, T);
     }
-    for (uint32_t li = layer_begin; li < d.num_layer && li < layer_end; ++li) {
+    // one sequence, one token: the persistent engine takes every layer of the step in ONE launch (wrk_v7_engine.hip)
+    uint32_t first_launch_layer = layer_begin;
+    if (T == 1 && engine_on()) {
+        const uint32_t l1 = std::min<uint32_t>(d.num_layer, layer_end);
+        if (layer_begin < l1) {
+            const int32_t rc = wrk_v7_engine_enqueue(engine, q, st, cursor0_batch, layer_begin, l1, s.x, s.x, s.att_v0);
+            if (rc != WRK_OK) return rc;
+        }
+        first_launch_layer = l1;
+    }
+    for (uint32_t li = first_launch_layer; li < d.num_layer && li < layer_end; ++li) {
         const wrk_v7_layer_desc& L = layers[li];
         float* lst = st->layer_ptr(li);
         // batch-1 decode folds LN + token shift into the prologue of the matvec that consumes them (5 launches per layer
@@ -623,7 +599,7 @@ int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_
                      matvec(q, &k6, 1, ctx->num_cu, true) == 0;
         }
         // split head (4 workgroups per head, group norm in W_o's prologue): batch-1 decode whose W_o launch the dmv kernels take
-        static const bool want_split = [] { const char* e = getenv("WRK_SPLIT_HEAD"); return !(e && e[0] == '0'); }();
+        const bool want_split = split_head_env_on();
         const uint32_t state_stride = (S + 2) * D;       // floats between the state rows of consecutive sequences
         bool split_head = want_split && single && d.lora_w >= 8 && d.lora_a >= 8 && d.lora_g >= 8 && d.lora_v >= 8 && d.lora_g <= 512;
         if (split_head) {

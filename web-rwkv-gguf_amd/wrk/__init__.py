@@ -124,6 +124,7 @@ HIP_SYMBOLS = {
     "wrk_v7_state_back": (C.c_int32, [_P, _P, C.c_uint32, _f32p]),
     "wrk_v7_infer": (C.c_int32, [_P, _P, _P, _u32p, C.POINTER(C.c_uint16), _u32p, C.c_uint32, _u32p, C.c_uint32, _f32p, _u32p, C.c_uint32]),
     "wrk_v7_model_set_frame_dtype": (C.c_int32, [_P, _P, C.c_uint32]),
+    "wrk_v7_model_engine_status": (C.c_int32, [_P, _P, C.c_char_p, C.c_size_t]),
     "wrk_v7_infer_layer": (C.c_int32, [_P, _P, _P, C.c_uint32, _P, _P, _u32p, C.c_uint32, C.c_uint32]),
     "wrk_v7_frame_read": (C.c_int32, [_P, _P, C.c_char_p, C.c_uint32, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "wrk_v7_generate_greedy": (C.c_int32, [_P, _P, _P, _u32p, C.c_uint32, C.c_uint32, _u32p, _f32p, _f32p, C.c_uint32]),
@@ -686,6 +687,14 @@ class Runtime:
         """`Bundle::<f16>` (F16, default) or `Bundle::<f32>` (F32) -- v7.rs:281-364 is generic over the activation type."""
         self.ctx.check(hip.wrk_v7_model_set_frame_dtype(self.ctx.h, self.model, dtype))
         self.frame_dtype = dtype
+
+    def engine_status(self):
+        """(exists, reason) of the persistent batch-1 decode engine of this model (RWKV-7)."""
+        buf = C.create_string_buffer(512)
+        rc = hip.wrk_v7_model_engine_status(self.ctx.h, self.model, buf, 512)
+        if rc < 0:
+            self.ctx.check(rc)
+        return rc == 1, buf.value.decode()
 
     def infer_layer(self, layer: int, x: np.ndarray, v_first: Optional[np.ndarray], cursors, mode: int = 0):
         """Teacher-forced run of one layer on the layer input `x` [T, D] (and the layer-0 value `v_first`)."""
