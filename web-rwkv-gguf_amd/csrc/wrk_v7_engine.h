@@ -36,19 +36,25 @@ struct EngShape {
     uint32_t x_from_granules;                       // unused (layer_begin's input is always the plain x vector)
 };
 
+// matrix pointers of a layer (read by the loader wave a layer ahead, and by the head workgroups once per layer)
 struct EngLayer {
     const uint8_t *w_r, *w_k, *w_v, *w1, *a1, *g1, *v1;      // K1 (v1 unused on layer 0)
     const uint8_t *w2, *a2, *g2, *v2;                        // K2, F16 rows
     const uint8_t *w_o, *ffn_k, *ffn_v;
-    const void *ln1_w, *ln1_b, *ln2_w, *ln2_b;
-    const void* mix[6];                                      // x_r, x_w, x_k, x_v, x_a, x_g
-    const void *w0, *a0, *v0, *r_k, *k_k, *k_a, *gn_w, *gn_b, *ffn_x_k;
-    float scale[ENG_K1_JOBS], scale_o, scale_fk, scale_fv;   // wrk_matrix::out_scale
 };
+// The f16 vectors of every layer are PACKED into one buffer [L][ENG_NV][D] when the engine is built, so that a stage computes their
+// addresses instead of loading them: a pointer fetched through a table is a dependent scalar round trip at the head of a stage, and the
+// compiler must repeat it after every barrier (the barrier's asm clobbers memory) -- the first build spent ~1 us per stage there.
+enum { ENG_V_LN1W, ENG_V_LN1B, ENG_V_LN2W, ENG_V_LN2B, ENG_V_MIX0, ENG_V_W0 = ENG_V_MIX0 + 6, ENG_V_A0, ENG_V_V0, ENG_V_RK, ENG_V_KK, ENG_V_KA,
+       ENG_V_GNW, ENG_V_GNB, ENG_V_FFNXK, ENG_NV };
+// wrk_matrix::out_scale of a layer's matrices: [L][ENG_NS] floats: K1 jobs 0..6, then W_o, ffn key, ffn value
+enum { ENG_S_O = ENG_K1_JOBS, ENG_S_FK, ENG_S_FV, ENG_NS = 16 };
 
 struct EngArgs {
     EngShape S;
     const EngLayer* layers;         // [num_layer]
+    const void* vecs;               // f16 [num_layer][ENG_NV][D]
+    const float* scal;              // [num_layer][ENG_NS]
     unsigned long long* gran;       // granule buffer, zeroed before every launch
     const void* x_in;               // f16 [D]: input of layer_begin (embedding LN output)
     void* x_out;                    // f16 [D]: output of layer_end - 1

@@ -94,6 +94,40 @@ __device__ __forceinline__ void eng_copy_in(const void* src, uint32_t n16, ENG_L
     for (uint32_t q = lane; q < n16; q += 64) dst[q] = ((const u32x4*)src)[q];
 }
 
+// The ffn vector of K6 straight into a wave's register-resident inputs: lane L of wave w multiplies chunk c of every row, i.e. elements
+// [lo, lo + 16) and [hi, hi + 16) of the vector = 2 x 4 pieces of granules.  Each compute wave polls exactly the quarter of the vector
+// it multiplies (K is split over the four waves): no LDS round trip, no wave waits for another wave's quarter.
+template <int KIND>
+__device__ __forceinline__ bool eng_sweep_x(const unsigned long long* g, uint32_t c, uint32_t tag, XRegs& x) {
+    uint32_t lo, hi;
+    chunk_xoff<KIND>(c, lo, hi);
+    const u32x4* pl = (const u32x4*)g + (lo >> 2);
+    const u32x4* ph = (const u32x4*)g + (hi >> 2);
+    u32x4 v[8];
+    for (uint32_t spins = 0; spins < ENG_SPIN_MAX; ++spins) {
+        asm volatile(
+            "global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %8, off offset:16 sc1\n\tglobal_load_dwordx4 %2, %8, off offset:32 sc1\n\t"
+            "global_load_dwordx4 %3, %8, off offset:48 sc1\n\tglobal_load_dwordx4 %4, %9, off sc1\n\tglobal_load_dwordx4 %5, %9, off offset:16 sc1\n\t"
+            "global_load_dwordx4 %6, %9, off offset:32 sc1\n\tglobal_load_dwordx4 %7, %9, off offset:48 sc1\n\ts_waitcnt vmcnt(0)"
+            : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+            : "v"(pl), "v"(ph)
+            : "memory");
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ok &= (v[i].y == tag) & (v[i].w == tag);
+        if (__all(ok)) {
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const u32x4 q = {v[2 * h].x, v[2 * h].z, v[2 * h + 1].x, v[2 * h + 1].z};
+                x.v[h] = __builtin_bit_cast(f16x8, q);
+            }
+            return true;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return false;
+}
+
 // ------------------------------------------------------------------ loader wave
 // `bytes` of weights at `src` (16-byte aligned, a multiple of 16) -> LDS at byte offset lds_off, in 1 KiB pieces; lanes beyond the end
 // re-read the last 16 bytes into the slot's padding.  Returns the number of pieces issued.
@@ -404,10 +438,7 @@ __global__ void __launch_bounds__(ENG_THREADS) v7_engine_kernel(const EngArgs A,
             ENG_BAR();
             if (*abort_flag) break;
             ENG_BAR(); ENG_BAR(); ENG_BAR();
-            // K6: the ffn vector
-            ok = eng_gather(A.gran + S.g_k, F >> 2, eng_tag(l, 3), (ENG_LDS uint32_t*)xs, lane);
-            if (!ok && lane == 0) { *abort_flag = 1; atomicOr(A.fail, 16u); }
-            ENG_STAMP(l, 4);
+            // K6: the compute waves poll their own quarters of the ffn vector
             ENG_BAR();
             if (*abort_flag) break;
             ENG_BAR(); ENG_BAR();
@@ -426,27 +457,42 @@ __global__ void __launch_bounds__(ENG_THREADS) v7_engine_kernel(const EngArgs A,
         b = min(wave * q, nrows);
         e = min(b + q, nrows);
     };
-    // K2 thread roles (head_kernel): (row, part) for the LoRA dots, (i, g4) for the state
-    const uint32_t row = tid >> 2, prt = tid & 3u, ci64 = tid & 63u, g4 = tid >> 6;
-    const uint32_t c0 = is_head ? head * S64 : 0u, ch = c0 + row;
+    const uint32_t c0 = is_head ? head * S64 : 0u;
     float vfirst_keep = 0.0f;
-    if (is_head && S.layer_begin > 0) vfirst_keep = (float)((const f16*)A.v_first)[ch];
+    if (is_head && S.layer_begin > 0) vfirst_keep = (float)((const f16*)A.v_first)[c0 + (tid >> 2)];
+    const uint32_t tid_all = tid;
 
     for (uint32_t l = S.layer_begin; l < S.layer_end; ++l) {
-        const EngLayer& L = A.layers[l];
+        // Per-thread indices are re-derived every layer from an OPAQUE copy of the thread id: otherwise the compiler hoists every address
+        // and offset that does not depend on the layer out of the loop and keeps ~100 registers of them alive through all stages, which
+        // (with the 104 registers of K2's in-flight rows) spilled.
+        uint32_t tid = tid_all;
+        asm volatile("" : "+v"(tid));
+        const uint32_t lane = tid & 63u;
+        // K2 thread roles (head_kernel): (row, part) for the LoRA dots, (i, g4) for the state
+        const uint32_t row = tid >> 2, prt = tid & 3u, ci64 = tid & 63u, g4 = tid >> 6;
+        const uint32_t ch = c0 + row;
         float* lst = layer_state(l);
         const bool layer0 = l == 0;
+        // everything of this layer that lives behind a pointer is fetched HERE, once, into registers (the barriers clobber memory: a
+        // field read later would be a fresh dependent scalar round trip at the head of a stage)
+        const f16* lv_base = (const f16*)A.vecs + (size_t)l * ENG_NV * D;
+        auto lvec = [&](uint32_t idx) { return lv_base + (size_t)idx * D; };
+        const float* scl = A.scal + (size_t)l * ENG_NS;
+        const float sc_k1 = scl[j1 < ENG_K1_JOBS ? j1 : 0u], sc_o = scl[ENG_S_O], sc_fk = scl[ENG_S_FK], sc_fv = scl[ENG_S_FV];
+        const uint8_t *p_w2 = nullptr, *p_a2 = nullptr, *p_g2 = nullptr, *p_v2 = nullptr;
+        if (is_head) { const EngLayer& L = A.layers[l]; p_w2 = L.w2; p_a2 = L.a2; p_g2 = L.g2; p_v2 = L.v2; }
 
         // ---- requests that depend on nothing: LN1 operands
         f16x8 wv[VPT], bv[VPT], mv[VPT];
         f32x4 pv[VPT][2];
         {
-            const f16* mixp = (const f16*)L.mix[j1 < ENG_K1_JOBS ? S.k1[j1].mix : 0u];
+            const f16* mixp = lvec(ENG_V_MIX0 + (j1 < ENG_K1_JOBS ? S.k1[j1].mix : 0u));
 #pragma unroll
             for (int v = 0; v < VPT; ++v) {
                 const uint32_t i = min(tid + 256u * v, nvec - 1);
-                wv[v] = *(const f16x8*)((const f16*)L.ln1_w + i * 8);
-                bv[v] = *(const f16x8*)((const f16*)L.ln1_b + i * 8);
+                wv[v] = *(const f16x8*)(lvec(ENG_V_LN1W) + i * 8);
+                bv[v] = *(const f16x8*)(lvec(ENG_V_LN1B) + i * 8);
                 mv[v] = *(const f16x8*)(mixp + i * 8);
                 pv[v][0] = *(const f32x4*)(lst + i * 8);
                 pv[v][1] = *(const f32x4*)(lst + i * 8 + 4);
@@ -462,7 +508,7 @@ __global__ void __launch_bounds__(ENG_THREADS) v7_engine_kernel(const EngArgs A,
             const EngJob& J = S.k1[j1];
             uint32_t rb, re;
             wave_rows(k1_rows, rb, re);
-            const EngFin fin{J.act, L.scale[j1], nullptr, 1.0f};
+            const EngFin fin{J.act, sc_k1, nullptr, 1.0f};
             const lds_u8* slot = smem + S.lds_slot1;
             if (J.f16) {
                 const uint32_t gb = S.g_k1 + J.gbase;
@@ -475,17 +521,20 @@ __global__ void __launch_bounds__(ENG_THREADS) v7_engine_kernel(const EngArgs A,
             }
         }
         ENG_STAMP(l, 3);
-        // (heads) requests of K2 that depend on nothing: LoRA up-projection rows, per-channel vectors, the state -- in flight across the
-        // K1 -> K2 hand-off
-        f16x8 lw[4], la[4], lv[4], lg[8];
-        float Sreg[16];
-        f16 h_w0 = 0, h_a0 = 0, h_kk = 0, h_ka = 0, h_v0 = 0, h_gnw = 0, h_gnb = 0, h_rk = 0;
-        float* st = lst + (size_t)D + c0 + ci64;            // S[j][c0 + i] at st[j * D]
+        ENG_BAR();                                          // K1 done: slot, xs free
+
+        // ================================================ K2 (one workgroup per head): head_kernel's arithmetic
         if (is_head) {
-            const f16* w2r = (const f16*)(L.w2 + (size_t)ch * S.rb_w2);
-            const f16* a2r = (const f16*)(L.a2 + (size_t)ch * S.rb_a2);
-            const f16* g2r = (const f16*)(L.g2 + (size_t)ch * S.rb_g2);
-            const f16* v2r = layer0 ? w2r : (const f16*)(L.v2 + (size_t)ch * S.rb_v2);
+            // (heads) requests of K2 that depend on nothing: LoRA up-projection rows, per-channel vectors, the state -- in flight across the
+            // K1 -> K2 hand-off
+            f16x8 lw[4], la[4], lv[4], lg[8];
+            float Sreg[16];
+            f16 h_w0 = 0, h_a0 = 0, h_kk = 0, h_ka = 0, h_v0 = 0, h_gnw = 0, h_gnb = 0, h_rk = 0;
+            float* st = lst + (size_t)D + c0 + ci64;            // S[j][c0 + i] at st[j * D]
+            const f16* w2r = (const f16*)(p_w2 + (size_t)ch * S.rb_w2);
+            const f16* a2r = (const f16*)(p_a2 + (size_t)ch * S.rb_a2);
+            const f16* g2r = (const f16*)(p_g2 + (size_t)ch * S.rb_g2);
+            const f16* v2r = layer0 ? w2r : (const f16*)(p_v2 + (size_t)ch * S.rb_v2);
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
                 lw[n] = *(const f16x8*)(w2r + min(prt * 8 + 32 * n, S.rw - 8));
@@ -494,17 +543,11 @@ __global__ void __launch_bounds__(ENG_THREADS) v7_engine_kernel(const EngArgs A,
             }
 #pragma unroll
             for (int n = 0; n < 8; ++n) lg[n] = *(const f16x8*)(g2r + min(prt * 8 + 32 * n, S.rg - 8));
-            h_w0 = ((const f16*)L.w0)[ch]; h_a0 = ((const f16*)L.a0)[ch]; h_kk = ((const f16*)L.k_k)[ch]; h_ka = ((const f16*)L.k_a)[ch];
-            h_v0 = ((const f16*)(layer0 ? L.w0 : L.v0))[ch];
-            h_gnw = ((const f16*)L.gn_w)[c0 + ci64]; h_gnb = ((const f16*)L.gn_b)[c0 + ci64]; h_rk = ((const f16*)L.r_k)[c0 + ci64];
+            h_w0 = lvec(ENG_V_W0)[ch]; h_a0 = lvec(ENG_V_A0)[ch]; h_kk = lvec(ENG_V_KK)[ch]; h_ka = lvec(ENG_V_KA)[ch];
+            h_v0 = lvec(ENG_V_V0)[ch];
+            h_gnw = lvec(ENG_V_GNW)[c0 + ci64]; h_gnb = lvec(ENG_V_GNB)[c0 + ci64]; h_rk = lvec(ENG_V_RK)[c0 + ci64];
 #pragma unroll
             for (int jj = 0; jj < 16; ++jj) Sreg[jj] = st[(size_t)(g4 * 16 + jj) * D];
-        }
-
-        ENG_BAR();                                          // K1 done: slot, xs free
-
-        // ================================================ K2 (one workgroup per head): head_kernel's arithmetic
-        if (is_head) {
             ENG_LDS float* sh_r = k2f; ENG_LDS float* sh_w = k2f + 64; ENG_LDS float* sh_k = k2f + 128; ENG_LDS float* sh_v = k2f + 192;
             ENG_LDS float* sh_a = k2f + 256; ENG_LDS float* sh_b = k2f + 320; ENG_LDS float* sh_g = k2f + 384; ENG_LDS float* sh_kk = k2f + 448;
             ENG_LDS float* sh_red = k2f + 512;              // [4][64]
@@ -520,11 +563,16 @@ __global__ void __launch_bounds__(ENG_THREADS) v7_engine_kernel(const EngArgs A,
             const float gnw = (float)h_gnw, gnb = (float)h_gnb, rkw = (float)h_rk;
             const float shift = (float)lnbuf[c0 + ci64];
             {
+                // (compiler barriers: one dot's LDS reads at a time -- hoisting all twenty chunk reads costs 80 registers and spills)
                 const float dw = eng_lora_dot<4>(lw, aw, S.rw, prt);
+                asm volatile("" ::: "memory");
                 const float da = eng_lora_dot<4>(la, aa, S.ra, prt);
+                asm volatile("" ::: "memory");
                 const float dg = eng_lora_dot<8>(lg, ag, S.rg, prt);
+                asm volatile("" ::: "memory");
                 float dv = 0.0f;
                 if (!layer0) dv = eng_lora_dot<4>(lv, av, S.rv, prt);
+                asm volatile("" ::: "memory");
                 if (layer0) vfirst_keep = v;                                                  // blit(att_v, att_v0): an f16 value
                 if (prt == 0) {
                     const float w = r16(w0 + r16(dw));
@@ -596,9 +644,9 @@ __global__ void __launch_bounds__(ENG_THREADS) v7_engine_kernel(const EngArgs A,
         {
             uint32_t rb, re;
             wave_rows(k3_rows, rb, re);
-            const EngFin fin{WRK_ACT_NONE, L.scale_o, xraw0, 1.0f};
+            const EngFin fin{WRK_ACT_NONE, sc_o, xraw0, 1.0f};
             const uint32_t gb = S.g_x1;
-            eng_rows<QK, R16, XD, 4>(smem + S.lds_slot3, S.rb_d, D, xs, k3_row0, rb, re, fin, A.gran, eng_tag(l, 2), [&](uint32_t r) { return gb + (r >> 1); },
+            eng_rows<QK, R16, XD, 2>(smem + S.lds_slot3, S.rb_d, D, xs, k3_row0, rb, re, fin, A.gran, eng_tag(l, 2), [&](uint32_t r) { return gb + (r >> 1); },
                                   (f16*)nullptr, lane);
         }
         // requests of K5's prologue (the ffn shift state was last written by the previous token)
@@ -607,9 +655,9 @@ __global__ void __launch_bounds__(ENG_THREADS) v7_engine_kernel(const EngArgs A,
 #pragma unroll
             for (int v = 0; v < VPT; ++v) {
                 const uint32_t i = min(tid + 256u * v, nvec - 1);
-                wv[v] = *(const f16x8*)((const f16*)L.ln2_w + i * 8);
-                bv[v] = *(const f16x8*)((const f16*)L.ln2_b + i * 8);
-                mv[v] = *(const f16x8*)((const f16*)L.ffn_x_k + i * 8);
+                wv[v] = *(const f16x8*)(lvec(ENG_V_LN2W) + i * 8);
+                bv[v] = *(const f16x8*)(lvec(ENG_V_LN2B) + i * 8);
+                mv[v] = *(const f16x8*)(lvec(ENG_V_FFNXK) + i * 8);
                 pv[v][0] = *(const f32x4*)(rowf + i * 8);
                 pv[v][1] = *(const f32x4*)(rowf + i * 8 + 4);
             }
@@ -625,7 +673,7 @@ __global__ void __launch_bounds__(ENG_THREADS) v7_engine_kernel(const EngArgs A,
         {
             uint32_t rb, re;
             wave_rows(k5_rows, rb, re);
-            const EngFin fin{WRK_ACT_SQUARED_RELU, L.scale_fk, nullptr, 1.0f};
+            const EngFin fin{WRK_ACT_SQUARED_RELU, sc_fk, nullptr, 1.0f};
             const uint32_t gb = S.g_k;
             eng_rows<QK, R16, XD, 4>(smem + S.lds_slot5, S.rb_d, D, xs, k5_row0, rb, re, fin, A.gran, eng_tag(l, 3), [&](uint32_t r) { return gb + (r >> 1); },
                                   (f16*)nullptr, lane);
@@ -634,24 +682,28 @@ __global__ void __launch_bounds__(ENG_THREADS) v7_engine_kernel(const EngArgs A,
         ENG_BAR();                                          // K5 done
 
         // ================================================ K6: x = x1 + ffn_value . k   (K over the four waves)
-        ENG_BAR();                                          // k in xs (F elements), ffn value rows in their slot
-        if (*abort_flag) break;
-        ENG_STAMP(l, 10);
         {
+            // every compute wave polls its own K quarter of the ffn vector straight into registers (eng_sweep_x)
             const uint32_t kpad = (F + 15u) & ~15u;
             const uint32_t nch = num_chunks<QK>(F, kpad);
             const uint32_t cbase = lane + 64u * wave;
             XRegs x[1][XD];
+            bool swept = true;
 #pragma unroll
             for (int ci = 0; ci < XD; ++ci) {
                 const uint32_t c = cbase + 256u * ci;
-                x[0][ci] = lds_x<QK>(xs, min(c, nch - 1));
+                x[0][ci].s[0] = x[0][ci].s[1] = 0.0f;
+                if (swept) swept = eng_sweep_x<QK>(A.gran + S.g_k, min(c, nch - 1), eng_tag(l, 3), x[0][ci]);
                 if (c >= nch) {
                     const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
                     x[0][ci].v[0] = x[0][ci].v[1] = x[0][ci].v[2] = x[0][ci].v[3] = z;
                 }
                 x_sums<QK>(x[0][ci]);
             }
+            if (!swept && lane == 0) { *abort_flag = 1; atomicOr(A.fail, 16u); }
+            ENG_BAR();                                      // ffn value rows in their slot (loader), every wave has its inputs
+            if (*abort_flag) break;
+            ENG_STAMP(l, 10);
             const lds_u8* slot = smem + S.lds_slot6;
             for (uint32_t ri = 0; ri < k6_rows; ri += 4) {
                 Raw raw[4][XD];
@@ -678,7 +730,7 @@ __global__ void __launch_bounds__(ENG_THREADS) v7_engine_kernel(const EngArgs A,
             float o = 0.0f;
             if (k6_rows) {
                 const uint32_t p = min(tid, k6_rows - 1);
-                o = ((part[p * 4] + part[p * 4 + 1]) + (part[p * 4 + 2] + part[p * 4 + 3])) * L.scale_fv;
+                o = ((part[p * 4] + part[p * 4 + 1]) + (part[p * 4 + 2] + part[p * 4 + 3])) * sc_fv;
                 o = r16(o) + (float)xraw1[r];
                 if ((l + 1) % S.rescale == 0) o = r16(o) * 0.5f;                              // affine(x, 0.5) after the layer
             }
@@ -702,6 +754,8 @@ struct wrk_v7_engine {
     wrk_v7_model* m = nullptr;
     wrk::EngShape S{};
     wrk::EngLayer* layers = nullptr;        // device [L]
+    void* vecs = nullptr;                   // device f16 [L][ENG_NV][D]
+    float* scal = nullptr;                  // device [L][ENG_NS]
     uint32_t* wg_head = nullptr;            // device [nwg]
     unsigned long long* gran = nullptr;     // device
     uint32_t* fail = nullptr;               // device (pinned readable through memcpy)
@@ -831,6 +885,7 @@ int32_t wrk_v7_engine_create(wrk_v7_model* m, wrk_v7_engine** out) {
     S.rescale = d.rescale ? d.rescale : 0xffffffffu;
     S.state_rows = 64 + 2;
 
+    std::vector<float> hs(m->layers.size() * ENG_NS, 1.0f);
     auto fail_alloc = [&](hipError_t er) { wrk_v7_engine_destroy(e); return wrk_fail(ctx, WRK_E_OOM, "decode engine: %s", hipGetErrorString(er)); };
     hipError_t er;
     std::vector<EngLayer> hl(m->layers.size());
@@ -841,15 +896,24 @@ int32_t wrk_v7_engine_create(wrk_v7_model* m, wrk_v7_engine** out) {
         o.v1 = li ? L.v1->data : L.a1->data;
         o.w2 = L.w2->data; o.a2 = L.a2->data; o.g2 = L.g2->data; o.v2 = li ? L.v2->data : L.a2->data;
         o.w_o = L.w_o->data; o.ffn_k = L.ffn_w_k->data; o.ffn_v = L.ffn_w_v->data;
-        o.ln1_w = L.ln1_w->ptr; o.ln1_b = L.ln1_b->ptr; o.ln2_w = L.ln2_w->ptr; o.ln2_b = L.ln2_b->ptr;
-        const wrk_buf* mx[6] = {L.x_r, L.x_w, L.x_k, L.x_v, L.x_a, L.x_g};
-        for (int i = 0; i < 6; ++i) o.mix[i] = mx[i]->ptr;
-        o.w0 = L.w0->ptr; o.a0 = L.a0->ptr; o.v0 = li ? L.v0->ptr : L.w0->ptr; o.r_k = L.r_k->ptr; o.k_k = L.k_k->ptr; o.k_a = L.k_a->ptr;
-        o.gn_w = L.gn_w->ptr; o.gn_b = L.gn_b->ptr; o.ffn_x_k = L.ffn_x_k->ptr;
         const wrk_matrix* k1m[ENG_K1_JOBS] = {L.w_r, L.w_k, L.w_v, L.w1, L.a1, L.g1, li ? L.v1 : L.a1};
-        for (int j = 0; j < ENG_K1_JOBS; ++j) o.scale[j] = k1m[j]->out_scale;
-        o.scale_o = L.w_o->out_scale; o.scale_fk = L.ffn_w_k->out_scale; o.scale_fv = L.ffn_w_v->out_scale;
+        float* sc = hs.data() + li * ENG_NS;
+        for (int j = 0; j < ENG_K1_JOBS; ++j) sc[j] = k1m[j]->out_scale;
+        sc[ENG_S_O] = L.w_o->out_scale; sc[ENG_S_FK] = L.ffn_w_k->out_scale; sc[ENG_S_FV] = L.ffn_w_v->out_scale;
     }
+    // the f16 vectors of every layer, packed
+    if ((er = hipMalloc((void**)&e->vecs, hl.size() * ENG_NV * D * 2)) != hipSuccess) return fail_alloc(er);
+    for (size_t li = 0; li < m->layers.size(); ++li) {
+        const auto& L = m->layers[li];
+        const wrk_buf* src[ENG_NV] = {L.ln1_w, L.ln1_b, L.ln2_w, L.ln2_b, L.x_r, L.x_w, L.x_k, L.x_v, L.x_a, L.x_g, L.w0, L.a0, li ? L.v0 : L.w0,
+                                      L.r_k, L.k_k, L.k_a, L.gn_w, L.gn_b, L.ffn_x_k};
+        for (int i = 0; i < ENG_NV; ++i) {
+            if (!src[i] || src[i]->bytes < (size_t)D * 2) { wrk_v7_engine_destroy(e); return no("a layer vector is missing"); }
+            if ((er = hipMemcpy((char*)e->vecs + (li * ENG_NV + i) * (size_t)D * 2, src[i]->ptr, (size_t)D * 2, hipMemcpyDeviceToDevice)) != hipSuccess) return fail_alloc(er);
+        }
+    }
+    if ((er = hipMalloc((void**)&e->scal, hs.size() * 4)) != hipSuccess) return fail_alloc(er);
+    if ((er = hipMemcpy(e->scal, hs.data(), hs.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(er);
     if ((er = hipMalloc((void**)&e->layers, hl.size() * sizeof(EngLayer))) != hipSuccess) return fail_alloc(er);
     if ((er = hipMemcpy(e->layers, hl.data(), hl.size() * sizeof(EngLayer), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(er);
     std::vector<uint32_t> hh(NWG, ENG_NO_HEAD);
@@ -884,6 +948,8 @@ int32_t wrk_v7_engine_create(wrk_v7_model* m, wrk_v7_engine** out) {
 void wrk_v7_engine_destroy(wrk_v7_engine* e) {
     if (!e) return;
     if (e->layers) hipFree(e->layers);
+    if (e->vecs) hipFree(e->vecs);
+    if (e->scal) hipFree(e->scal);
     if (e->wg_head) hipFree(e->wg_head);
     if (e->gran) hipFree(e->gran);
     if (e->fail) hipFree(e->fail);
@@ -898,7 +964,7 @@ int32_t wrk_v7_engine_enqueue(wrk_v7_engine* e, hipStream_t q, wrk_v7_state* st,
     EngArgs A{};
     A.S = e->S;
     A.S.layer_begin = l0; A.S.layer_end = l1; A.S.batch = batch;
-    A.layers = e->layers; A.gran = e->gran; A.x_in = x_in; A.x_out = x_out; A.v_first = v_first;
+    A.layers = e->layers; A.vecs = e->vecs; A.scal = e->scal; A.gran = e->gran; A.x_in = x_in; A.x_out = x_out; A.v_first = v_first;
     A.state = st->data; A.num_batch = st->num_batch; A.fail = e->fail; A.stamps = e->stamps; A.stamp_layer = std::min(5u, l1 - 1);
     // every polled word zeroed before every launch (a memset node, replayed first): tags are > 0 and unique within a launch
     WRK_HIP(ctx, hipMemsetAsync(e->gran, 0, (size_t)e->S.g_total * 8, q));
