@@ -423,6 +423,10 @@ def main():
             quant[l] = {"int8": wrk.QUANT_INT8, "nf4": wrk.QUANT_NF4}[kind]
     runtime = wrk.Runtime(ctx, reader, num_batch=B, weights=wrk.WEIGHTS_INLINE, quant=quant or None)
     load_s = time.time() - t0
+    engine = None
+    if args.model not in CONFIGS_V6 and B == 1 and args.mode == 1:
+        ok, why = runtime.engine_status()       # the persistent batch-1 decode engine (one launch per token) or the five-launch layer
+        engine = "on" if ok and os.environ.get("WRK_ENGINE", "1") != "0" else f"off ({why or 'WRK_ENGINE=0'})"
     first = [(17 + 101 * g) % (runtime.info.num_vocab - 1) for g in streams]
     token_bytes = runtime.token_bytes(B)
 
@@ -460,7 +464,7 @@ def main():
                                     if args.model in CONFIGS_V6 else
                                     f"RWKV-7 World {args.model} Q4_K_M ({'llama.cpp mix: Q4_K + Q6_K attn/ffn value' if args.mixed else 'Q4_K matrices'}, Q6_K head, F16 LoRA) batch={B} greedy decode, ") +
                                    f"{'fused kernels' if args.mode == 1 else 'one kernel per reference op'} under hipGraph",
-                       "streams_per_gpu": B, "pipelines_per_gpu": args.groups, "streams": world * B, "parallelism": f"replicas x{world}" if world > 1 else "single",
+                       **({"decode_engine": engine} if engine else {}), "streams_per_gpu": B, "pipelines_per_gpu": args.groups, "streams": world * B, "parallelism": f"replicas x{world}" if world > 1 else "single",
                        **({"rehearsal": f"device map {args.device_map}, {args.dist_backend} barrier: ranks SHARE GPUs, not a scaling number"} if args.device_map else {})},
             # per GPU: every replica streams its own copy of the weights
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -7,7 +7,6 @@
 namespace wrk {
 
 constexpr int ENG_K1_JOBS = 7;                  // r, k, v, w1, a1, g1, v1
-constexpr uint32_t ENG_THREADS = 384;           // 4 compute waves + gather wave + loader wave
 constexpr uint32_t ENG_NO_HEAD = 0xffffffffu;
 
 // one matrix of stage K1; the same for every layer (pointers live in EngLayer)

@@ -267,78 +267,88 @@ __device__ __forceinline__ void eng_rows(const lds_u8* slot, uint32_t row_bytes,
 }
 
 // LN + token shift of the layer input (dmv_body PRO 1, one input vector): x (LDS, f16) -> xs = mix(LN(x), prev, mixw), ln_out = LN(x).
-// Two barriers inside.  VPT vectors of 8 channels per thread.
+// Two barriers inside.  The first four waves do the work (the 256-thread mapping of the launches: same partial sums); `active` = this
+// wave is one of them.  VPT vectors of 8 channels per thread.
 template <int VPT>
-__device__ __forceinline__ void eng_ln_mix(const ENG_LDS f16* xraw, ENG_LDS f16* xs, ENG_LDS f16* ln_out, ENG_LDS float* red, uint32_t K, float eps,
+__device__ __forceinline__ void eng_ln_mix(bool active, const ENG_LDS f16* xraw, ENG_LDS f16* xs, ENG_LDS f16* ln_out, ENG_LDS float* red, uint32_t K, float eps,
                                            const f16x8 (&wv)[VPT], const f16x8 (&bv)[VPT], const f16x8 (&mv)[VPT], const f32x4 (&pv)[VPT][2],
                                            uint32_t tid, uint32_t lane, uint32_t wave) {
     const uint32_t nvec = K >> 3;
     f16x8 xv[VPT];
+    float c0 = 0.0f;
+    if (active) {
 #pragma unroll
-    for (int v = 0; v < VPT; ++v) xv[v] = *(const ENG_LDS f16x8*)(xraw + min(tid + 256u * v, nvec - 1) * 8);
-    const float c0 = (float)xraw[0];
-    float s1 = 0.0f, s2 = 0.0f;
+        for (int v = 0; v < VPT; ++v) xv[v] = *(const ENG_LDS f16x8*)(xraw + min(tid + 256u * v, nvec - 1) * 8);
+        c0 = (float)xraw[0];
+        float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
-    for (int v = 0; v < VPT; ++v)
-        if (tid + 256u * v < nvec)
+        for (int v = 0; v < VPT; ++v)
+            if (tid + 256u * v < nvec)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { const float dl = (float)xv[v][e] - c0; s1 += dl; s2 = __builtin_fmaf(dl, dl, s2); }
-    s1 = wave_sum(s1);
-    s2 = wave_sum(s2);
-    if (lane == 0) { red[wave] = s1; red[4 + wave] = s2; }
+                for (int e = 0; e < 8; ++e) { const float dl = (float)xv[v][e] - c0; s1 += dl; s2 = __builtin_fmaf(dl, dl, s2); }
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        if (lane == 0) { red[wave] = s1; red[4 + wave] = s2; }
+    }
     ENG_BAR();
-    const float a1 = (red[0] + red[1]) + (red[2] + red[3]);
-    const float a2 = (red[4] + red[5]) + (red[6] + red[7]);
-    const float md = a1 / (float)K;
-    const float mean = c0 + md;
-    const float dev = 1.0f / sqrtf(fmaxf(a2 / (float)K - md * md, 0.0f) + eps);
+    if (active) {
+        const float a1 = (red[0] + red[1]) + (red[2] + red[3]);
+        const float a2 = (red[4] + red[5]) + (red[6] + red[7]);
+        const float md = a1 / (float)K;
+        const float mean = c0 + md;
+        const float dev = 1.0f / sqrtf(fmaxf(a2 / (float)K - md * md, 0.0f) + eps);
 #pragma unroll
-    for (int v = 0; v < VPT; ++v) {
-        const uint32_t i = tid + 256u * v;
-        if (i >= nvec) continue;
-        f16x8 yv, o;
+        for (int v = 0; v < VPT; ++v) {
+            const uint32_t i = tid + 256u * v;
+            if (i >= nvec) continue;
+            f16x8 yv, o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            yv[e] = (f16)__builtin_fmaf(((float)xv[v][e] - mean) * dev, (float)wv[v][e], (float)bv[v][e]);
-            o[e] = (f16)wgsl_mix((float)yv[e], pv[v][e >> 2][e & 3], (float)mv[v][e]);
+            for (int e = 0; e < 8; ++e) {
+                yv[e] = (f16)__builtin_fmaf(((float)xv[v][e] - mean) * dev, (float)wv[v][e], (float)bv[v][e]);
+                o[e] = (f16)wgsl_mix((float)yv[e], pv[v][e >> 2][e & 3], (float)mv[v][e]);
+            }
+            *(ENG_LDS f16x8*)(xs + i * 8) = o;
+            *(ENG_LDS f16x8*)(ln_out + i * 8) = yv;
         }
-        *(ENG_LDS f16x8*)(xs + i * 8) = o;
-        *(ENG_LDS f16x8*)(ln_out + i * 8) = yv;
     }
     ENG_BAR();
 }
 
 // ------------------------------------------------------------------ the kernel
-// XD: 16-byte chunks per lane of a D-wide quantised row (D <= 2048 XD); R16: WRK_MATRIX_ROUND_F16; QK: kind of the big matrices
-template <int XD, bool R16, int QK>
-__global__ void __launch_bounds__(ENG_THREADS) v7_engine_kernel(const EngArgs A, const uint32_t* __restrict__ wg_head) {
+// XD: 16-byte chunks per lane of a D-wide quantised row (D <= 2048 XD); R16: WRK_MATRIX_ROUND_F16; QK: kind of the big matrices;
+// NCW: compute waves (8 or 14).  Wave NCW gathers, wave NCW + 1 loads.  A lone wave on a SIMD issues one vector instruction per ~4
+// cycles, and the stages are instruction-issue bound (~125 instructions per row): the first build (4 compute waves, one per SIMD) spent
+// 1.9 us on the 8 rows per wave of K1 -- hence as many compute waves as the register file allows.
+constexpr int ENG_K2_BARRIERS = 6;      // barriers of stage K2, the first one included
+template <int XD, bool R16, int QK, int NCW>
+__global__ void __launch_bounds__((NCW + 2) * 64) v7_engine_kernel(const EngArgs A, const uint32_t* __restrict__ wg_head) {
     extern __shared__ __attribute__((aligned(16))) unsigned char eng_smem_generic[];
     lds_u8* smem = (lds_u8*)eng_smem_generic;
     const EngShape& S = A.S;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const uint32_t tid_all = threadIdx.x;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid_all >> 6));
     const uint32_t wg = blockIdx.x;
     const uint32_t D = S.D, F = S.F;
-    const uint32_t head = wg_head[wg];
+    const uint32_t head = wg_head[2 * wg], k1r = wg_head[2 * wg + 1];       // head of this workgroup (or none); its rank among the K1 workgroups
     const bool is_head = head != ENG_NO_HEAD;
     ENG_LDS uint32_t* abort_flag = (ENG_LDS uint32_t*)(smem + S.lds_misc + 1008);
     ENG_LDS float* red = (ENG_LDS float*)(smem + S.lds_misc);                // 8 floats
-    ENG_LDS float* part = (ENG_LDS float*)(smem + S.lds_misc + 64);          // 32 rows x 4 waves
+    ENG_LDS float* part = (ENG_LDS float*)(smem + S.lds_misc + 64);          // 32 rows x 4 K quarters
     ENG_LDS f16* xraw0 = (ENG_LDS f16*)(smem + S.lds_xraw0);
     ENG_LDS f16* xraw1 = (ENG_LDS f16*)(smem + S.lds_xraw1);
-    ENG_LDS f16* xs = (ENG_LDS f16*)(smem + S.lds_xs);                       // also the first D elements of the ffn vector
+    ENG_LDS f16* xs = (ENG_LDS f16*)(smem + S.lds_xs);
     ENG_LDS f16* lnbuf = (ENG_LDS f16*)(smem + S.lds_ln);
-    // K2 scratch, behind xs inside the ffn vector's region
+    // K2 scratch, behind xs
     ENG_LDS f16* auxbuf = (ENG_LDS f16*)(smem + S.lds_xs + D * 2u);          // aux_w | aux_a | aux_g | aux_v | r[64] k[64] v[64]
     const uint32_t naux = S.rw + S.ra + S.rg + S.rv;
-    ENG_LDS float* k2f = (ENG_LDS float*)(smem + S.lds_xs + D * 2u + ((naux + 192u) * 2u + 15u & ~15u));      // 8 x 64 + 4 x 64 floats
+    ENG_LDS float* k2f = (ENG_LDS float*)(smem + S.lds_xs + D * 2u + ((naux + 192u) * 2u + 15u & ~15u));      // ENG_K2F floats
 
     // this workgroup's share of every stage
     uint32_t j1 = ENG_K1_JOBS;
 #pragma unroll
     for (int j = 0; j < ENG_K1_JOBS; ++j)
-        if (wg >= S.k1[j].wg0 && wg < S.k1[j].wg0 + S.k1[j].nwg) j1 = j;
-    const uint32_t k1_row0 = j1 < ENG_K1_JOBS ? (wg - S.k1[j1].wg0) * S.k1[j1].rows_per_wg : 0u;
+        if (k1r >= S.k1[j].wg0 && k1r < S.k1[j].wg0 + S.k1[j].nwg) j1 = j;
+    const uint32_t k1_row0 = j1 < ENG_K1_JOBS ? (k1r - S.k1[j1].wg0) * S.k1[j1].rows_per_wg : 0u;
     const uint32_t k1_rows = j1 < ENG_K1_JOBS ? min(S.k1[j1].rows_per_wg, S.k1[j1].rows - k1_row0) : 0u;
     const uint32_t k1_rb = j1 < ENG_K1_JOBS ? S.k1[j1].row_bytes : 0u;
     const uint32_t k3_row0 = wg * S.k3_rpw, k3_rows = k3_row0 < D ? min(S.k3_rpw, D - k3_row0) : 0u;
@@ -351,58 +361,92 @@ __global__ void __launch_bounds__(ENG_THREADS) v7_engine_kernel(const EngArgs A,
         return base + (size_t)k1_row0 * k1_rb;
     };
     auto k1_active = [&](uint32_t l) { return j1 < ENG_K1_JOBS && !(j1 == 6 && l == 0) && k1_rows > 0; };
-#define ENG_STAMP(l, k)                                                                                                            \
-    do {                                                                                                                           \
-        if (A.stamps && (l) == A.stamp_layer && lane == 0) A.stamps[((size_t)wg * 6 + wave) * ENG_STAMPS + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    // timeline (WRK_TIMING=1): every wave stamps the 100 MHz clock into LDS (a global store here would put a ~1 us store into the wave's
+    // vmcnt queue and distort what it measures); the stamps of the chosen layer are flushed when the layer is done
+    ENG_LDS unsigned long long* lds_stamps = (ENG_LDS unsigned long long*)(smem + S.lds_misc + 1024);      // [NCW + 2][24]
+#define ENG_STAMP(l, k)                                                                                                  \
+    do {                                                                                                                 \
+        if (A.stamps && (l) == A.stamp_layer && (tid_all & 63u) == 0) lds_stamps[wave * 24 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#define ENG_STAMP0(l, k) ENG_STAMP(l, k)
+#define ENG_FLUSH(l)                                                                                                     \
+    do {                                                                                                                 \
+        if (A.stamps && (l) == A.stamp_layer && (tid_all & 63u) < 24u)                                                   \
+            A.stamps[((size_t)wg * (NCW + 2) + wave) * 24 + (tid_all & 63u)] = lds_stamps[wave * 24 + (tid_all & 63u)];   \
     } while (0)
 
-    if (tid == 0) *abort_flag = 0;
+    if (A.stamps && tid_all < (NCW + 2) * 24) lds_stamps[tid_all] = 0;
+    if (tid_all == 0) *abort_flag = 0;
     ENG_BAR();
 
     // ================================================================== loader wave
-    if (wave == 5) {
+    if (wave == NCW + 1) {
+        const uint32_t lane = tid_all & 63u;
         uint32_t issued = 0, m1 = 0, m3 = 0, m5 = 0, m6 = 0;
         auto fill1 = [&](uint32_t l) { const EngLayer& L = A.layers[l]; issued += eng_fill(k1_src(L), k1_active(l) ? k1_rows * k1_rb : 0u, smem, S.lds_slot1, lane); m1 = issued; };
         auto fill3 = [&](uint32_t l) { const EngLayer& L = A.layers[l]; issued += eng_fill(L.w_o + (size_t)k3_row0 * S.rb_d, k3_rows * S.rb_d, smem, S.lds_slot3, lane); m3 = issued; };
         auto fill5 = [&](uint32_t l) { const EngLayer& L = A.layers[l]; issued += eng_fill(L.ffn_k + (size_t)k5_row0 * S.rb_d, k5_rows * S.rb_d, smem, S.lds_slot5, lane); m5 = issued; };
         auto fill6 = [&](uint32_t l) { const EngLayer& L = A.layers[l]; issued += eng_fill(L.ffn_v + (size_t)k6_row0 * S.rb_f, k6_rows * S.rb_f, smem, S.lds_slot6, lane); m6 = issued; };
         fill1(S.layer_begin); fill3(S.layer_begin); fill5(S.layer_begin); fill6(S.layer_begin);
+        // A slot is refilled (for the next layer) one barrier AFTER its stage has ended: behind the first barrier of the following stage,
+        // i.e. when that stage's gather is over -- a 37-piece DMA burst issued at the stage's end queued in this CU's memory pipeline
+        // right in front of the gather wave's polls (timeline of the first build: 2.7 us for a hand-off that takes 1 us).
+        uint32_t pending = 0;                               // 1, 3, 5, 6: slot whose stage has just ended; 0 none
+        auto refill = [&](uint32_t l) {
+            if (pending == 1) fill1(l + 1);
+            else if (pending == 3) fill3(l + 1);
+            else if (pending == 5) fill5(l + 1);
+            else if (pending == 6) fill6(l);                // issued inside the next layer's K1: `l` is already the next layer
+            pending = 0;
+        };
         for (uint32_t l = S.layer_begin; l < S.layer_end; ++l) {
             const bool more = l + 1 < S.layer_end;
             // K1
             eng_wait_vm(issued - m1);
             ENG_BAR();
             if (*abort_flag) break;
+            refill(l);
             ENG_BAR(); ENG_BAR(); ENG_BAR();
             ENG_STAMP(l, 0);
-            if (more) fill1(l + 1);
+            if (more) pending = 1;
             // K2
-            if (is_head) { ENG_BAR(); if (*abort_flag) break; ENG_BAR(); ENG_BAR(); ENG_BAR(); ENG_BAR(); ENG_BAR(); ENG_BAR(); }
+            if (is_head) {
+                ENG_BAR();
+                if (*abort_flag) break;
+                refill(l);
+#pragma unroll
+                for (int i = 1; i < ENG_K2_BARRIERS; ++i) ENG_BAR();
+            }
             // K3
             eng_wait_vm(issued - m3);
             ENG_BAR();
             if (*abort_flag) break;
+            refill(l);
             ENG_BAR();
-            if (more) fill3(l + 1);
+            if (more) pending = 3;
             // K5
             eng_wait_vm(issued - m5);
             ENG_BAR();
             if (*abort_flag) break;
+            refill(l);
             ENG_BAR(); ENG_BAR(); ENG_BAR();
-            if (more) fill5(l + 1);
+            if (more) pending = 5;
             // K6
             eng_wait_vm(issued - m6);
             ENG_BAR();
             if (*abort_flag) break;
+            refill(l);
             ENG_BAR(); ENG_BAR();
-            if (more) fill6(l + 1);
+            if (more) pending = 6;
+            ENG_FLUSH(l);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         return;
     }
 
     // ================================================================== gather wave
-    if (wave == 4) {
+    if (wave == NCW) {
+        const uint32_t lane = tid_all & 63u;
         for (uint32_t l = S.layer_begin; l < S.layer_end; ++l) {
             bool ok = true;
             // K1: the layer input
@@ -422,7 +466,8 @@ __global__ void __launch_bounds__(ENG_THREADS) v7_engine_kernel(const EngArgs A,
                 ENG_STAMP(l, 1);
                 ENG_BAR();
                 if (*abort_flag) break;
-                ENG_BAR(); ENG_BAR(); ENG_BAR(); ENG_BAR(); ENG_BAR(); ENG_BAR();
+#pragma unroll
+                for (int i = 1; i < ENG_K2_BARRIERS; ++i) ENG_BAR();
             }
             // K3: the gated head outputs
             ok = eng_gather(A.gran + S.g_o, D >> 2, eng_tag(l, 1), (ENG_LDS uint32_t*)xs, lane);
@@ -442,36 +487,36 @@ __global__ void __launch_bounds__(ENG_THREADS) v7_engine_kernel(const EngArgs A,
             ENG_BAR();
             if (*abort_flag) break;
             ENG_BAR(); ENG_BAR();
+            ENG_FLUSH(l);
         }
         return;
     }
 
-    // ================================================================== compute waves (256 threads)
+    // ================================================================== compute waves
     constexpr int VPT = XD;                                 // vectors of 8 channels per thread in the LN prologues
     constexpr int S64 = 64;
+    constexpr int MAXU = (16 + NCW - 1) / NCW;              // (matrix, 16-row block) units of K2's LoRA up-projections per wave
     const uint32_t nvec = D >> 3;
     const float eps = S.ln_eps;
-    // rows of a wave in the KS == 1 stages: a contiguous, even-sized block
+    const bool ln_wave = wave < 4;                          // the 256 threads of the launches' mapping
+    // rows of a wave in the KS == 1 stages: a contiguous block of row pairs
     auto wave_rows = [&](uint32_t nrows, uint32_t& b, uint32_t& e) {
-        const uint32_t q = (((nrows + 3u) >> 2) + 1u) & ~1u;
+        const uint32_t q = 2u * (((nrows + 1u) / 2u + NCW - 1u) / NCW);
         b = min(wave * q, nrows);
         e = min(b + q, nrows);
     };
     const uint32_t c0 = is_head ? head * S64 : 0u;
-    float vfirst_keep = 0.0f;
-    if (is_head && S.layer_begin > 0) vfirst_keep = (float)((const f16*)A.v_first)[c0 + (tid >> 2)];
-    const uint32_t tid_all = tid;
+    float vfirst_keep = 0.0f;                               // wave 0, lane = channel of the head
+    if (is_head && S.layer_begin > 0 && wave == 0) vfirst_keep = (float)((const f16*)A.v_first)[c0 + (tid_all & 63u)];
 
+    unsigned long long clk0 = 0, rt0 = 0;
+    if (A.stamps && wg == 0 && tid_all == 0) { clk0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
     for (uint32_t l = S.layer_begin; l < S.layer_end; ++l) {
         // Per-thread indices are re-derived every layer from an OPAQUE copy of the thread id: otherwise the compiler hoists every address
-        // and offset that does not depend on the layer out of the loop and keeps ~100 registers of them alive through all stages, which
-        // (with the 104 registers of K2's in-flight rows) spilled.
+        // and offset that does not depend on the layer out of the loop and keeps ~100 registers of them alive through all stages.
         uint32_t tid = tid_all;
         asm volatile("" : "+v"(tid));
         const uint32_t lane = tid & 63u;
-        // K2 thread roles (head_kernel): (row, part) for the LoRA dots, (i, g4) for the state
-        const uint32_t row = tid >> 2, prt = tid & 3u, ci64 = tid & 63u, g4 = tid >> 6;
-        const uint32_t ch = c0 + row;
         float* lst = layer_state(l);
         const bool layer0 = l == 0;
         // everything of this layer that lives behind a pointer is fetched HERE, once, into registers (the barriers clobber memory: a
@@ -480,13 +525,11 @@ __global__ void __launch_bounds__(ENG_THREADS) v7_engine_kernel(const EngArgs A,
         auto lvec = [&](uint32_t idx) { return lv_base + (size_t)idx * D; };
         const float* scl = A.scal + (size_t)l * ENG_NS;
         const float sc_k1 = scl[j1 < ENG_K1_JOBS ? j1 : 0u], sc_o = scl[ENG_S_O], sc_fk = scl[ENG_S_FK], sc_fv = scl[ENG_S_FV];
-        const uint8_t *p_w2 = nullptr, *p_a2 = nullptr, *p_g2 = nullptr, *p_v2 = nullptr;
-        if (is_head) { const EngLayer& L = A.layers[l]; p_w2 = L.w2; p_a2 = L.a2; p_g2 = L.g2; p_v2 = L.v2; }
 
-        // ---- requests that depend on nothing: LN1 operands
+        // ---- requests that depend on nothing: LN1 operands (the four LN waves)
         f16x8 wv[VPT], bv[VPT], mv[VPT];
         f32x4 pv[VPT][2];
-        {
+        if (ln_wave) {
             const f16* mixp = lvec(ENG_V_MIX0 + (j1 < ENG_K1_JOBS ? S.k1[j1].mix : 0u));
 #pragma unroll
             for (int v = 0; v < VPT; ++v) {
@@ -498,159 +541,181 @@ __global__ void __launch_bounds__(ENG_THREADS) v7_engine_kernel(const EngArgs A,
                 pv[v][1] = *(const f32x4*)(lst + i * 8 + 4);
             }
         }
-        // ================================================ K1
-        ENG_BAR();                                          // x in xraw0, K1 weights in their slot
-        if (*abort_flag) break;
-        ENG_STAMP(l, 1);
-        eng_ln_mix<VPT>(xraw0, xs, lnbuf, red, D, eps, wv, bv, mv, pv, tid, lane, wave);
-        ENG_STAMP(l, 2);
-        if (k1_active(l)) {
-            const EngJob& J = S.k1[j1];
-            uint32_t rb, re;
-            wave_rows(k1_rows, rb, re);
-            const EngFin fin{J.act, sc_k1, nullptr, 1.0f};
-            const lds_u8* slot = smem + S.lds_slot1;
-            if (J.f16) {
-                const uint32_t gb = S.g_k1 + J.gbase;
-                eng_rows<WRK_MAT_F16, false, 4 * XD, 2>(slot, k1_rb, D, xs, k1_row0, rb, re, fin, A.gran, eng_tag(l, 0),
-                                                     [&](uint32_t r) { return gb + (r >> 1); }, (f16*)nullptr, lane);
-            } else {
-                const uint32_t gb = S.g_k1 + S.g_aux + J.gbase * 32u;
-                eng_rows<QK, R16, XD, 4>(slot, k1_rb, D, xs, k1_row0, rb, re, fin, A.gran, eng_tag(l, 0),
-                                      [&](uint32_t r) { return gb + (r >> 6) * 96u + ((r & 63u) >> 1); }, (f16*)nullptr, lane);
-            }
-        }
-        ENG_STAMP(l, 3);
-        ENG_BAR();                                          // K1 done: slot, xs free
 
-        // ================================================ K2 (one workgroup per head): head_kernel's arithmetic
-        if (is_head) {
-            // (heads) requests of K2 that depend on nothing: LoRA up-projection rows, per-channel vectors, the state -- in flight across the
-            // K1 -> K2 hand-off
-            f16x8 lw[4], la[4], lv[4], lg[8];
-            float Sreg[16];
-            f16 h_w0 = 0, h_a0 = 0, h_kk = 0, h_ka = 0, h_v0 = 0, h_gnw = 0, h_gnb = 0, h_rk = 0;
-            float* st = lst + (size_t)D + c0 + ci64;            // S[j][c0 + i] at st[j * D]
-            const f16* w2r = (const f16*)(p_w2 + (size_t)ch * S.rb_w2);
-            const f16* a2r = (const f16*)(p_a2 + (size_t)ch * S.rb_a2);
-            const f16* g2r = (const f16*)(p_g2 + (size_t)ch * S.rb_g2);
-            const f16* v2r = layer0 ? w2r : (const f16*)(p_v2 + (size_t)ch * S.rb_v2);
-#pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                lw[n] = *(const f16x8*)(w2r + min(prt * 8 + 32 * n, S.rw - 8));
-                la[n] = *(const f16x8*)(a2r + min(prt * 8 + 32 * n, S.ra - 8));
-                lv[n] = *(const f16x8*)(v2r + min(prt * 8 + 32 * n, (layer0 ? S.rw : S.rv) - 8));
-            }
-#pragma unroll
-            for (int n = 0; n < 8; ++n) lg[n] = *(const f16x8*)(g2r + min(prt * 8 + 32 * n, S.rg - 8));
-            h_w0 = lvec(ENG_V_W0)[ch]; h_a0 = lvec(ENG_V_A0)[ch]; h_kk = lvec(ENG_V_KK)[ch]; h_ka = lvec(ENG_V_KA)[ch];
-            h_v0 = lvec(ENG_V_V0)[ch];
-            h_gnw = lvec(ENG_V_GNW)[c0 + ci64]; h_gnb = lvec(ENG_V_GNB)[c0 + ci64]; h_rk = lvec(ENG_V_RK)[c0 + ci64];
-#pragma unroll
-            for (int jj = 0; jj < 16; ++jj) Sreg[jj] = st[(size_t)(g4 * 16 + jj) * D];
-            ENG_LDS float* sh_r = k2f; ENG_LDS float* sh_w = k2f + 64; ENG_LDS float* sh_k = k2f + 128; ENG_LDS float* sh_v = k2f + 192;
-            ENG_LDS float* sh_a = k2f + 256; ENG_LDS float* sh_b = k2f + 320; ENG_LDS float* sh_g = k2f + 384; ENG_LDS float* sh_kk = k2f + 448;
-            ENG_LDS float* sh_red = k2f + 512;              // [4][64]
-            ENG_BAR();                                      // LoRA intermediates and r, k, v of this head in auxbuf
+        if (!is_head) {
+            // ================================================ K1
+            ENG_BAR();                                      // x in xraw0, K1 weights in their slot
             if (*abort_flag) break;
-            ENG_STAMP(l, 4);
-            const ENG_LDS f16* aw = auxbuf, *aa = auxbuf + S.rw, *ag = auxbuf + S.rw + S.ra, *av = auxbuf + S.rw + S.ra + S.rg;
-            const ENG_LDS f16* hr = auxbuf + naux, *hk = hr + 64, *hv = hr + 128;
-            const float w0 = (float)h_w0, a0 = (float)h_a0, kkw = (float)h_kk, kaw = (float)h_ka;
-            const float kraw = (float)hk[row], rraw = (float)hr[row];
-            float v = (float)hv[row];
-            const float v0w = layer0 ? 0.0f : (float)h_v0, vfirst = layer0 ? 0.0f : vfirst_keep;
-            const float gnw = (float)h_gnw, gnb = (float)h_gnb, rkw = (float)h_rk;
-            const float shift = (float)lnbuf[c0 + ci64];
-            {
-                // (compiler barriers: one dot's LDS reads at a time -- hoisting all twenty chunk reads costs 80 registers and spills)
-                const float dw = eng_lora_dot<4>(lw, aw, S.rw, prt);
-                asm volatile("" ::: "memory");
-                const float da = eng_lora_dot<4>(la, aa, S.ra, prt);
-                asm volatile("" ::: "memory");
-                const float dg = eng_lora_dot<8>(lg, ag, S.rg, prt);
-                asm volatile("" ::: "memory");
-                float dv = 0.0f;
-                if (!layer0) dv = eng_lora_dot<4>(lv, av, S.rv, prt);
-                asm volatile("" ::: "memory");
-                if (layer0) vfirst_keep = v;                                                  // blit(att_v, att_v0): an f16 value
-                if (prt == 0) {
-                    const float w = r16(w0 + r16(dw));
-                    const float a = r16(act_sigmoid(a0 + r16(da)));
-                    const float g = r16(dg);
-                    if (layer0) ((f16*)A.v_first)[ch] = (f16)v;
-                    else {
-                        const float vv = r16(act_sigmoid(v0w + r16(dv)));
-                        v = r16(wgsl_mix(v, vfirst, vv));
-                    }
-                    sh_w[row] = __expf(-0.606531f * act_sigmoid(w));
-                    sh_a[row] = a;
-                    sh_g[row] = g;
-                    sh_v[row] = v;
-                    sh_r[row] = rraw;
-                    sh_kk[row] = r16(kkw * kraw);
-                    sh_k[row] = r16(kraw * (1.0f + (a - 1.0f) * kaw));
+            ENG_STAMP0(l, 1);
+            eng_ln_mix<VPT>(ln_wave, xraw0, xs, lnbuf, red, D, eps, wv, bv, mv, pv, tid, lane, wave);
+            ENG_STAMP0(l, 2);
+            if (k1_active(l)) {
+                const EngJob& J = S.k1[j1];
+                uint32_t rb, re;
+                wave_rows(k1_rows, rb, re);
+                const EngFin fin{J.act, sc_k1, nullptr, 1.0f};
+                const lds_u8* slot = smem + S.lds_slot1;
+                if (J.f16) {
+                    const uint32_t gb = S.g_k1 + J.gbase;
+                    eng_rows<WRK_MAT_F16, false, 4 * XD, 2>(slot, k1_rb, D, xs, k1_row0, rb, re, fin, A.gran, eng_tag(l, 0),
+                                                            [&](uint32_t r) { return gb + (r >> 1); }, (f16*)nullptr, lane);
+                } else {
+                    const uint32_t gb = S.g_k1 + S.g_aux + J.gbase * 32u;
+                    eng_rows<QK, R16, XD, 4>(slot, k1_rb, D, xs, k1_row0, rb, re, fin, A.gran, eng_tag(l, 0),
+                                             [&](uint32_t r) { return gb + (r >> 6) * 96u + ((r & 63u) >> 1); }, (f16*)nullptr, lane);
                 }
             }
-            if (g4 == 1) lst[c0 + ci64] = shift;                                               // att shift state <- LN1(x)
-            ENG_BAR();
-            if (g4 == 0) {
-                const float kkv = sh_kk[ci64];
+            ENG_STAMP0(l, 3);
+            ENG_BAR();                                      // K1 done: slot, xs free
+        } else {
+            // ================================================ K1 on a head workgroup: no rows; the LoRA up-projection rows, per-channel
+            // vectors and the state of K2 are requested NOW, a whole stage before they are needed (80 KB through one CU take 2 - 3 us)
+            const EngLayer& Lp = A.layers[l];
+            const uint8_t* p_m[4] = {Lp.w2, Lp.a2, Lp.g2, layer0 ? Lp.w2 : Lp.v2};
+            const uint32_t rbm[4] = {S.rb_w2, S.rb_a2, S.rb_g2, layer0 ? S.rb_w2 : S.rb_v2};
+            const uint32_t rkm[4] = {S.rw, S.ra, S.rg, layer0 ? S.rw : S.rv};
+            f16x8 lu[MAXU][8];
+#pragma unroll
+            for (int i = 0; i < MAXU; ++i) {
+                const uint32_t u = min(wave + (uint32_t)i * NCW, 15u), mi = u >> 2, bi = u & 3u;     // a wave without a second unit re-reads unit 15
+                const f16* rowp = (const f16*)(p_m[mi] + (size_t)(c0 + 16u * bi + (lane >> 2)) * rbm[mi]);
+#pragma unroll
+                for (int n = 0; n < 8; ++n) lu[i][n] = *(const f16x8*)(rowp + min((lane & 3u) * 8 + 32 * n, rkm[mi] - 8));
+            }
+            float Sreg[16];
+            const uint32_t ci64 = tid & 63u, g4 = tid >> 6;
+            float* st = lst + (size_t)D + c0 + ci64;            // S[j][c0 + i] at st[j * D]
+            if (ln_wave) {
+#pragma unroll
+                for (int jj = 0; jj < 16; ++jj) Sreg[jj] = st[(size_t)(g4 * 16 + jj) * D];
+            }
+            f16 h_w0 = 0, h_a0 = 0, h_kk = 0, h_ka = 0, h_v0 = 0, h_gnw = 0, h_gnb = 0, h_rk = 0;
+            if (wave == 0) {
+                const uint32_t cc = c0 + lane;
+                h_w0 = lvec(ENG_V_W0)[cc]; h_a0 = lvec(ENG_V_A0)[cc]; h_kk = lvec(ENG_V_KK)[cc]; h_ka = lvec(ENG_V_KA)[cc]; h_v0 = lvec(ENG_V_V0)[cc];
+                h_gnw = lvec(ENG_V_GNW)[cc]; h_gnb = lvec(ENG_V_GNB)[cc]; h_rk = lvec(ENG_V_RK)[cc];
+            }
+            ENG_BAR();                                      // x in xraw0
+            if (*abort_flag) break;
+            ENG_STAMP0(l, 1);
+            eng_ln_mix<VPT>(ln_wave, xraw0, xs, lnbuf, red, D, eps, wv, bv, mv, pv, tid, lane, wave);
+            ENG_STAMP0(l, 3);
+            ENG_BAR();                                      // K1 done
+
+            // ================================================ K2 (one workgroup per head): head_kernel's arithmetic
+            ENG_LDS float* sh_r = k2f; ENG_LDS float* sh_w = k2f + 64; ENG_LDS float* sh_k = k2f + 128; ENG_LDS float* sh_v = k2f + 192;
+            ENG_LDS float* sh_a = k2f + 256; ENG_LDS float* sh_b = k2f + 320; ENG_LDS float* sh_g = k2f + 384; ENG_LDS float* sh_kk = k2f + 448;
+            ENG_LDS float* sh_red = k2f + 512;              // [4][64]: sa partials
+            ENG_LDS float* sh_red2 = k2f + 768;             // [4][64]: y partials
+            ENG_LDS float* sh_d = k2f + 1024;               // [4][64]: LoRA dots (w, a, g, v) per channel
+            ENG_BAR();                                      // (1) LoRA intermediates and r, k, v of this head in auxbuf
+            if (*abort_flag) break;
+            ENG_STAMP0(l, 4);
+            {
+                const ENG_LDS f16* auxm[4] = {auxbuf, auxbuf + S.rw, auxbuf + S.rw + S.ra, layer0 ? auxbuf : auxbuf + S.rw + S.ra + S.rg};
+#pragma unroll
+                for (int i = 0; i < MAXU; ++i) {
+                    const uint32_t u = wave + (uint32_t)i * NCW;
+                    if (u < 16u) {
+                        const uint32_t mi = u >> 2, bi = u & 3u;
+                        const float dd = eng_lora_dot<8>(lu[i], auxm[mi], rkm[mi], lane & 3u);
+                        if ((lane & 3u) == 0) sh_d[mi * 64 + 16 * bi + (lane >> 2)] = dd;
+                    }
+                }
+            }
+            ENG_STAMP0(l, 16);
+            ENG_BAR();                                      // (2)
+            const ENG_LDS f16* hr = auxbuf + naux, *hk = hr + 64, *hv = hr + 128;
+            if (wave == 0) {                                // per-channel stage: lane = channel of the head
+                const float w0 = (float)h_w0, a0 = (float)h_a0, kkw = (float)h_kk, kaw = (float)h_ka;
+                const float kraw = (float)hk[lane], rraw = (float)hr[lane];
+                float v = (float)hv[lane];
+                const float v0w = layer0 ? 0.0f : (float)h_v0, vfirst = layer0 ? 0.0f : vfirst_keep;
+                const float dw = sh_d[lane], da = sh_d[64 + lane], dg = sh_d[128 + lane], dv = layer0 ? 0.0f : sh_d[192 + lane];
+                const float w = r16(w0 + r16(dw));                                               // add(w0, w)
+                const float a = r16(act_sigmoid(a0 + r16(da)));                                  // add_activate(.., Sigmoid)
+                const float g = r16(dg);
+                if (layer0) { vfirst_keep = v; ((f16*)A.v_first)[c0 + lane] = (f16)v; }          // blit(att_v, att_v0)
+                else {
+                    const float vv = r16(act_sigmoid(v0w + r16(dv)));
+                    v = r16(wgsl_mix(v, vfirst, vv));                                            // lerp(att_v0, att_v, att_vv, reversed)
+                }
+                sh_w[lane] = __expf(-0.606531f * act_sigmoid(w));                                // act_w (time_mix_v7.wgsl:68-70)
+                sh_g[lane] = g;
+                sh_v[lane] = v;
+                sh_r[lane] = rraw;
+                const float kkv = r16(kkw * kraw);                                               // mul(k_k, kk)
+                sh_k[lane] = r16(kraw * (1.0f + (a - 1.0f) * kaw));                              // control_k_v7
+                // kk <- l2_norm(kk) over the head; a~ = -kk, b~ = kk * a
                 const float nrm = 1.0f / sqrtf(wave_sum(kkv * kkv) + S.l2_eps);
                 const float kkn = r16(kkv * nrm);
-                const float a = sh_a[ci64];
-                sh_a[ci64] = -kkn;
-                sh_b[ci64] = kkn * a;
+                sh_a[lane] = -kkn;
+                sh_b[lane] = kkn * a;
+                sh_kk[lane] = kkv;
             }
-            ENG_BAR();
-            float sa = 0.0f;
+            if (wave == 1) lst[c0 + lane] = (float)lnbuf[c0 + lane];                             // att shift state <- LN1(x)
+            ENG_STAMP0(l, 17);
+            ENG_BAR();                                      // (3)
+            if (ln_wave) {
+                float sa = 0.0f;
+                f32x4 av[4];                               // sh_a[16 g4 .. +15]: the same for every lane, four 16-byte reads
 #pragma unroll
-            for (int jj = 0; jj < 16; ++jj) sa = __builtin_fmaf(Sreg[jj], sh_a[g4 * 16 + jj], sa);
-            sh_red[g4 * 64 + ci64] = sa;
-            ENG_BAR();
-            sa = (sh_red[ci64] + sh_red[64 + ci64]) + (sh_red[128 + ci64] + sh_red[192 + ci64]);
-            const float vv = sh_v[ci64];
-            float y = 0.0f;
+                for (int q = 0; q < 4; ++q) av[q] = *(const ENG_LDS f32x4*)(sh_a + g4 * 16 + 4 * q);
 #pragma unroll
-            for (int jj = 0; jj < 16; ++jj) {
-                const int j = g4 * 16 + jj;
-                const float s = Sreg[jj] * sh_w[j] + sh_k[j] * vv + sa * sh_b[j];
-                st[(size_t)j * D] = s;
-                y = __builtin_fmaf(sh_r[j], s, y);
+                for (int jj = 0; jj < 16; ++jj) sa = __builtin_fmaf(Sreg[jj], av[jj >> 2][jj & 3], sa);
+                sh_red[g4 * 64 + ci64] = sa;
             }
-            ENG_BAR();
-            sh_red[g4 * 64 + ci64] = y;
-            ENG_BAR();
-            if (g4 == 0) {
-                y = r16((sh_red[ci64] + sh_red[64 + ci64]) + (sh_red[128 + ci64] + sh_red[192 + ci64]));
+            ENG_BAR();                                      // (4)
+            if (ln_wave) {
+                const float sa = (sh_red[ci64] + sh_red[64 + ci64]) + (sh_red[128 + ci64] + sh_red[192 + ci64]);
+                const float vv = sh_v[ci64];
+                float y = 0.0f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 wq = *(const ENG_LDS f32x4*)(sh_w + g4 * 16 + 4 * q), kq4 = *(const ENG_LDS f32x4*)(sh_k + g4 * 16 + 4 * q);
+                    const f32x4 bq = *(const ENG_LDS f32x4*)(sh_b + g4 * 16 + 4 * q), rq4 = *(const ENG_LDS f32x4*)(sh_r + g4 * 16 + 4 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int jj = 4 * q + e, j = g4 * 16 + jj;
+                        const float sn = Sreg[jj] * wq[e] + kq4[e] * vv + sa * bq[e];
+                        st[(size_t)j * D] = sn;
+                        y = __builtin_fmaf(rq4[e], sn, y);
+                    }
+                }
+                sh_red2[g4 * 64 + ci64] = y;
+            }
+            ENG_STAMP0(l, 18);
+            ENG_BAR();                                      // (5)
+            if (wave == 0) {
+                float y = r16((sh_red2[lane] + sh_red2[64 + lane]) + (sh_red2[128 + lane] + sh_red2[192 + lane]));     // att_x <- y (f16 store)
                 const float mean = wave_sum(y) * (1.0f / S64);
                 const float dl = y - mean;
                 const float var = wave_sum(dl * dl) * (1.0f / S64) + S.gn_eps;
-                float o = r16(__builtin_fmaf(dl * (1.0f / sqrtf(var)), gnw, gnb));
-                const float xx = wave_sum(rkw * sh_k[ci64] * sh_r[ci64]);
-                o = r16(o + xx * vv);
-                o = sh_g[ci64] * o;
+                float o = r16(__builtin_fmaf(dl * (1.0f / sqrtf(var)), (float)h_gnw, (float)h_gnb));
+                const float xx = wave_sum((float)h_rk * sh_k[lane] * sh_r[lane]);
+                o = r16(o + xx * sh_v[lane]);
+                o = sh_g[lane] * o;
                 const float o_next = __shfl_down(o, 1, WAVE);
-                if ((ci64 & 1u) == 0) eng_store_granule(A.gran + S.g_o + ((c0 + ci64) >> 1), eng_tag(l, 1), pack_h2(o, o_next));
+                if ((lane & 1u) == 0) eng_store_granule(A.gran + S.g_o + ((c0 + lane) >> 1), eng_tag(l, 1), pack_h2(o, o_next));
             }
-            ENG_STAMP(l, 5);
-            ENG_BAR();                                      // K2 done
+            ENG_STAMP0(l, 5);
+            ENG_BAR();                                      // (6) K2 done
         }
 
         // ================================================ K3: x1 = x + W_o . o
         ENG_BAR();                                          // o in xs, W_o rows in their slot
         if (*abort_flag) break;
-        ENG_STAMP(l, 6);
+        ENG_STAMP0(l, 6);
         {
             uint32_t rb, re;
             wave_rows(k3_rows, rb, re);
             const EngFin fin{WRK_ACT_NONE, sc_o, xraw0, 1.0f};
             const uint32_t gb = S.g_x1;
             eng_rows<QK, R16, XD, 2>(smem + S.lds_slot3, S.rb_d, D, xs, k3_row0, rb, re, fin, A.gran, eng_tag(l, 2), [&](uint32_t r) { return gb + (r >> 1); },
-                                  (f16*)nullptr, lane);
+                                     (f16*)nullptr, lane);
         }
         // requests of K5's prologue (the ffn shift state was last written by the previous token)
-        {
+        if (ln_wave) {
             float* rowf = lst + (size_t)(srows - 1) * D;
 #pragma unroll
             for (int v = 0; v < VPT; ++v) {
@@ -662,74 +727,82 @@ __global__ void __launch_bounds__(ENG_THREADS) v7_engine_kernel(const EngArgs A,
                 pv[v][1] = *(const f32x4*)(rowf + i * 8 + 4);
             }
         }
-        ENG_STAMP(l, 7);
+        ENG_STAMP0(l, 7);
         ENG_BAR();                                          // K3 done
 
         // ================================================ K5: k = relu(ffn_key . mix(LN2(x1)))^2
         ENG_BAR();                                          // x1 in xraw1, ffn key rows in their slot
         if (*abort_flag) break;
-        ENG_STAMP(l, 8);
-        eng_ln_mix<VPT>(xraw1, xs, lnbuf, red, D, eps, wv, bv, mv, pv, tid, lane, wave);
+        ENG_STAMP0(l, 8);
+        eng_ln_mix<VPT>(ln_wave, xraw1, xs, lnbuf, red, D, eps, wv, bv, mv, pv, tid, lane, wave);
+        ENG_STAMP0(l, 14);
         {
             uint32_t rb, re;
             wave_rows(k5_rows, rb, re);
             const EngFin fin{WRK_ACT_SQUARED_RELU, sc_fk, nullptr, 1.0f};
             const uint32_t gb = S.g_k;
             eng_rows<QK, R16, XD, 4>(smem + S.lds_slot5, S.rb_d, D, xs, k5_row0, rb, re, fin, A.gran, eng_tag(l, 3), [&](uint32_t r) { return gb + (r >> 1); },
-                                  (f16*)nullptr, lane);
+                                     (f16*)nullptr, lane);
         }
-        ENG_STAMP(l, 9);
+        ENG_STAMP0(l, 9);
         ENG_BAR();                                          // K5 done
 
-        // ================================================ K6: x = x1 + ffn_value . k   (K over the four waves)
+        // ================================================ K6: x = x1 + ffn_value . k   (K over four waves, rows over NCW / 4 groups)
         {
             // every compute wave polls its own K quarter of the ffn vector straight into registers (eng_sweep_x)
+            constexpr uint32_t NG = NCW / 4;                // row groups
+            const uint32_t kq = wave & 3u, grp = wave >> 2;
+            const bool k6_wave = grp < NG;
+            const uint32_t rq = (k6_rows + NG - 1) / NG;
+            const uint32_t g_b = min(grp * rq, k6_rows), g_e = min(g_b + rq, k6_rows);
             const uint32_t kpad = (F + 15u) & ~15u;
             const uint32_t nch = num_chunks<QK>(F, kpad);
-            const uint32_t cbase = lane + 64u * wave;
+            const uint32_t cbase = lane + 64u * kq;
             XRegs x[1][XD];
             bool swept = true;
 #pragma unroll
             for (int ci = 0; ci < XD; ++ci) {
                 const uint32_t c = cbase + 256u * ci;
                 x[0][ci].s[0] = x[0][ci].s[1] = 0.0f;
-                if (swept) swept = eng_sweep_x<QK>(A.gran + S.g_k, min(c, nch - 1), eng_tag(l, 3), x[0][ci]);
-                if (c >= nch) {
-                    const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-                    x[0][ci].v[0] = x[0][ci].v[1] = x[0][ci].v[2] = x[0][ci].v[3] = z;
-                }
+                const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                x[0][ci].v[0] = x[0][ci].v[1] = x[0][ci].v[2] = x[0][ci].v[3] = z;
+                if (k6_wave && g_b < g_e && swept) swept = eng_sweep_x<QK>(A.gran + S.g_k, min(c, nch - 1), eng_tag(l, 3), x[0][ci]);
+                if (c >= nch) x[0][ci].v[0] = x[0][ci].v[1] = x[0][ci].v[2] = x[0][ci].v[3] = z;
                 x_sums<QK>(x[0][ci]);
             }
             if (!swept && lane == 0) { *abort_flag = 1; atomicOr(A.fail, 16u); }
+            ENG_STAMP0(l, 10);
             ENG_BAR();                                      // ffn value rows in their slot (loader), every wave has its inputs
             if (*abort_flag) break;
-            ENG_STAMP(l, 10);
+            ENG_STAMP0(l, 11);
             const lds_u8* slot = smem + S.lds_slot6;
-            for (uint32_t ri = 0; ri < k6_rows; ri += 4) {
-                Raw raw[4][XD];
+            if (k6_wave)
+                for (uint32_t ri = g_b; ri < g_e; ri += 4) {
+                    Raw raw[4][XD];
 #pragma unroll
-                for (int rb = 0; rb < 4; ++rb) {
-                    const lds_u8* rowp = slot + (size_t)min(ri + rb, k6_rows - 1) * S.rb_f;
+                    for (int rb = 0; rb < 4; ++rb) {
+                        const lds_u8* rowp = slot + (size_t)min(ri + rb, g_e - 1) * S.rb_f;
 #pragma unroll
-                    for (int ci = 0; ci < XD; ++ci) raw[rb][ci] = lds_raw<QK>(rowp, F, min(cbase + 256u * ci, nch - 1));
+                        for (int ci = 0; ci < XD; ++ci) raw[rb][ci] = lds_raw<QK>(rowp, F, min(cbase + 256u * ci, nch - 1));
+                    }
+#pragma unroll
+                    for (int rb = 0; rb < 4; ++rb) {
+                        float acc[1] = {0.0f};
+#pragma unroll
+                        for (int ci = 0; ci < XD; ++ci) dot_raw_tokens<QK, R16, 1, XD>(raw[rb][ci], min(cbase + 256u * ci, nch - 1), x, ci, acc);
+                        const float pvs = wave_sum(acc[0]);
+                        if (lane == 0 && ri + rb < g_e) part[(ri + rb) * 4 + kq] = pvs;
+                    }
                 }
-#pragma unroll
-                for (int rb = 0; rb < 4; ++rb) {
-                    float acc[1] = {0.0f};
-#pragma unroll
-                    for (int ci = 0; ci < XD; ++ci) dot_raw_tokens<QK, R16, 1, XD>(raw[rb][ci], min(cbase + 256u * ci, nch - 1), x, ci, acc);
-                    const float pvs = wave_sum(acc[0]);
-                    if (lane == 0 && ri + rb < k6_rows) part[(ri + rb) * 4 + wave] = pvs;
-                }
-            }
         }
+        ENG_STAMP0(l, 12);
         ENG_BAR();
-        if (tid < 64) {                                     // one wave finishes the (at most 32) rows
-            const bool valid = tid < k6_rows;
-            const uint32_t r = k6_row0 + min(tid, k6_rows ? k6_rows - 1 : 0u);
+        if (wave == 0) {                                    // one wave finishes the (at most 32) rows
+            const bool valid = lane < k6_rows;
+            const uint32_t r = k6_row0 + min(lane, k6_rows ? k6_rows - 1 : 0u);
             float o = 0.0f;
             if (k6_rows) {
-                const uint32_t p = min(tid, k6_rows - 1);
+                const uint32_t p = min(lane, k6_rows - 1);
                 o = ((part[p * 4] + part[p * 4 + 1]) + (part[p * 4 + 2] + part[p * 4 + 3])) * sc_fv;
                 o = r16(o) + (float)xraw1[r];
                 if ((l + 1) % S.rescale == 0) o = r16(o) * 0.5f;                              // affine(x, 0.5) after the layer
@@ -737,14 +810,22 @@ __global__ void __launch_bounds__(ENG_THREADS) v7_engine_kernel(const EngArgs A,
             const float o_next = __shfl_down(o, 1, WAVE);
             if (valid) {
                 lst[(size_t)(srows - 1) * D + r] = (float)lnbuf[r];                           // ffn shift state <- LN2(x1)
-                if ((tid & 1u) == 0) eng_store_granule(A.gran + S.g_x + (r >> 1), eng_tag(l, 4), pack_h2(o, o_next));
+                if ((lane & 1u) == 0) eng_store_granule(A.gran + S.g_x + (r >> 1), eng_tag(l, 4), pack_h2(o, o_next));
                 if (l + 1 == S.layer_end) ((f16*)A.x_out)[r] = (f16)o;
             }
         }
-        ENG_STAMP(l, 11);
+        ENG_STAMP0(l, 13);
         ENG_BAR();                                          // K6 done
+        ENG_FLUSH(l);
+    }
+    if (A.stamps && wg == 0 && tid_all == 0) {              // shader clock over the launch: (cycles, 100 MHz ticks) behind the timeline
+        unsigned long long* tail = A.stamps + (size_t)S.nwg * 16 * 24;
+        tail[0] = __builtin_amdgcn_s_memtime() - clk0;
+        tail[1] = __builtin_amdgcn_s_memrealtime() - rt0;
     }
 #undef ENG_STAMP
+#undef ENG_STAMP0
+#undef ENG_FLUSH
 }
 
 }  // namespace wrk
@@ -761,11 +842,21 @@ struct wrk_v7_engine {
     uint32_t* fail = nullptr;               // device (pinned readable through memcpy)
     unsigned long long* stamps = nullptr;   // device, WRK_TIMING=1
     bool r16 = false;
-    int xd = 1;
+    int xd = 1, ncw = 8;
     uint32_t quant = 0;
 };
 
 static uint32_t up(uint32_t v, uint32_t a) { return (v + a - 1) / a * a; }
+
+typedef void (*eng_fn)(const wrk::EngArgs, const uint32_t*);
+static eng_fn eng_kernel(int xd, bool r16, int ncw) {
+    using namespace wrk;
+#define ENG_PICK(XD_, R_) (ncw == 14 ? (eng_fn)v7_engine_kernel<XD_, R_, WRK_MAT_Q4_K, 14> : (eng_fn)v7_engine_kernel<XD_, R_, WRK_MAT_Q4_K, 8>)
+    if (xd == 1) return r16 ? ENG_PICK(1, true) : ENG_PICK(1, false);
+    return r16 ? ENG_PICK(2, true) : ENG_PICK(2, false);
+#undef ENG_PICK
+}
+static const void* eng_kernel_fn(int xd, bool r16, int ncw) { return (const void*)eng_kernel(xd, r16, ncw); }
 
 int32_t wrk_v7_engine_create(wrk_v7_model* m, wrk_v7_engine** out) {
     using namespace wrk;
@@ -779,7 +870,7 @@ int32_t wrk_v7_engine_create(wrk_v7_model* m, wrk_v7_engine** out) {
     if (d.lora_w % 8 || d.lora_a % 8 || d.lora_g % 8 || d.lora_v % 8 || d.lora_w < 8 || d.lora_a < 8 || d.lora_g < 8 || d.lora_v < 8 ||
         d.lora_w > 128 || d.lora_a > 128 || d.lora_v > 128 || d.lora_g > 256 || ((d.lora_w + d.lora_a + d.lora_g + d.lora_v) % 16))
         return no("LoRA ranks");
-    if (NWG < H || NWG < 64) return no("too few compute units");
+    if (NWG < 2 * H || NWG < 64) return no("too few compute units");
     // every big matrix of one quantised kind (Q4_K: the headline configuration), LoRA matrices F16, one rounding mode
     uint32_t quant = 0xffffffffu, flags = 0xffffffffu;
     for (size_t li = 0; li < m->layers.size(); ++li) {
@@ -827,18 +918,19 @@ int32_t wrk_v7_engine_create(wrk_v7_model* m, wrk_v7_engine** out) {
     for (auto& j : jd) total += (double)j.rows * j.rb;
     uint32_t slot1 = 0;
     bool placed = false;
-    for (double target = total / NWG; target < total; target *= 1.03) {
+    const uint32_t NK1 = NWG - H;                                      // the head workgroups take no K1 rows (they fetch K2's operands meanwhile)
+    for (double target = total / NK1; target < total; target *= 1.03) {
         uint32_t used = 0, worst = 0;
         uint32_t rpw[ENG_K1_JOBS], nw[ENG_K1_JOBS];
         for (int j = 0; j < ENG_K1_JOBS; ++j) {
             uint32_t r = (uint32_t)(target / jd[j].rb);
-            r = std::max(8u, r / 8 * 8);
+            r = std::max(2u, r / 2 * 2);
             rpw[j] = r;
             nw[j] = (jd[j].rows + r - 1) / r;
             used += nw[j];
             worst = std::max(worst, std::min(r, jd[j].rows) * jd[j].rb);
         }
-        if (used > NWG) continue;
+        if (used > NK1) continue;
         uint32_t w0 = 0;
         for (int j = 0; j < ENG_K1_JOBS; ++j) {
             S.k1[j] = EngJob{jd[j].rows, jd[j].rb, jd[j].f16, jd[j].act, jd[j].mix, w0, nw[j], rpw[j], jd[j].gbase, jd[j].headed};
@@ -863,9 +955,9 @@ int32_t wrk_v7_engine_create(wrk_v7_model* m, wrk_v7_engine** out) {
     S.lds_xraw0 = take(D * 2);
     S.lds_xraw1 = take(D * 2);
     const uint32_t naux = S.rw + S.ra + S.rg + S.rv;
-    S.lds_xs = take(std::max(F * 2, D * 2 + up((naux + 192) * 2, 16) + 768 * 4));      // the ffn vector; K2's scratch lives behind its first D elements
+    S.lds_xs = take(D * 2 + up((naux + 192) * 2, 16) + 1280 * 4);      // a stage's input vector (D elements); K2's scratch lives behind it
     S.lds_ln = take(D * 2);
-    S.lds_misc = take(1024);
+    S.lds_misc = take(4096);
     S.lds_total = off;
     int lds_max = 0;
     hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, ctx->device);
@@ -916,30 +1008,32 @@ int32_t wrk_v7_engine_create(wrk_v7_model* m, wrk_v7_engine** out) {
     if ((er = hipMemcpy(e->scal, hs.data(), hs.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(er);
     if ((er = hipMalloc((void**)&e->layers, hl.size() * sizeof(EngLayer))) != hipSuccess) return fail_alloc(er);
     if ((er = hipMemcpy(e->layers, hl.data(), hl.size() * sizeof(EngLayer), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(er);
-    std::vector<uint32_t> hh(NWG, ENG_NO_HEAD);
-    for (uint32_t h = 0; h < H; ++h) hh[(size_t)h * NWG / H] = h;
-    if ((er = hipMalloc((void**)&e->wg_head, NWG * 4)) != hipSuccess) return fail_alloc(er);
-    if ((er = hipMemcpy(e->wg_head, hh.data(), NWG * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(er);
+    std::vector<uint32_t> hh(2 * NWG, ENG_NO_HEAD);                 // per workgroup: {head or none, rank among the K1 workgroups or none}
+    for (uint32_t h = 0; h < H; ++h) hh[2 * ((size_t)h * NWG / H)] = h;
+    for (uint32_t w = 0, r = 0; w < NWG; ++w)
+        if (hh[2 * w] == ENG_NO_HEAD) hh[2 * w + 1] = r++;
+    if ((er = hipMalloc((void**)&e->wg_head, hh.size() * 4)) != hipSuccess) return fail_alloc(er);
+    if ((er = hipMemcpy(e->wg_head, hh.data(), hh.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(er);
     if ((er = hipMalloc((void**)&e->gran, (size_t)S.g_total * 8)) != hipSuccess) return fail_alloc(er);
     if ((er = hipMalloc((void**)&e->fail, 256)) != hipSuccess) return fail_alloc(er);
     if ((er = hipMemset(e->fail, 0, 256)) != hipSuccess) return fail_alloc(er);
     const char* tm = getenv("WRK_TIMING");
     if (tm && tm[0] == '1') {
-        const size_t n = (size_t)NWG * 6 * ENG_STAMPS * 8;
+        const size_t n = (size_t)NWG * 16 * 24 * 8 + 64;
         if ((er = hipMalloc((void**)&e->stamps, n)) != hipSuccess) return fail_alloc(er);
         hipMemset(e->stamps, 0, n);
     }
-    // dynamic LDS above 64 KiB needs the attribute, per device
-    const void* fns[] = {(const void*)v7_engine_kernel<1, false, WRK_MAT_Q4_K>, (const void*)v7_engine_kernel<1, true, WRK_MAT_Q4_K>,
-                         (const void*)v7_engine_kernel<2, false, WRK_MAT_Q4_K>, (const void*)v7_engine_kernel<2, true, WRK_MAT_Q4_K>};
-    for (const void* f : fns)
-        if ((er = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_total)) != hipSuccess) {
-            wrk_v7_engine_destroy(e);
-            return wrk_fail(ctx, WRK_E_UNSUPPORTED, "decode engine: %u bytes of LDS refused (%s)", S.lds_total, hipGetErrorString(er));
-        }
+    // compute waves per workgroup: 8 (two per SIMD, <= 168 registers) or 14 (<= 128 registers)
+    { const char* ev = getenv("WRK_ENGINE_WAVES"); e->ncw = (ev && atoi(ev) == 14) ? 14 : 8; }
+    const void* fn = eng_kernel_fn(e->xd, e->r16, e->ncw);
+    // dynamic LDS above 64 KiB needs the attribute (per device: set on every build of an engine)
+    if ((er = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_total)) != hipSuccess) {
+        wrk_v7_engine_destroy(e);
+        return wrk_fail(ctx, WRK_E_UNSUPPORTED, "decode engine: %u bytes of LDS refused (%s)", S.lds_total, hipGetErrorString(er));
+    }
     // one workgroup per CU, all resident
     int per_cu = 0;
-    er = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fns[(e->xd == 2 ? 2 : 0) + (e->r16 ? 1 : 0)], (int)ENG_THREADS, S.lds_total);
+    er = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, (e->ncw + 2) * 64, S.lds_total);
     if (er != hipSuccess || per_cu < 1) { wrk_v7_engine_destroy(e); return no("the kernel is not resident with this much LDS"); }
     *out = e;
     return WRK_OK;
@@ -968,15 +1062,8 @@ int32_t wrk_v7_engine_enqueue(wrk_v7_engine* e, hipStream_t q, wrk_v7_state* st,
     A.state = st->data; A.num_batch = st->num_batch; A.fail = e->fail; A.stamps = e->stamps; A.stamp_layer = std::min(5u, l1 - 1);
     // every polled word zeroed before every launch (a memset node, replayed first): tags are > 0 and unique within a launch
     WRK_HIP(ctx, hipMemsetAsync(e->gran, 0, (size_t)e->S.g_total * 8, q));
-    const dim3 grid(e->S.nwg), block(ENG_THREADS);
-    const uint32_t lds = e->S.lds_total;
-    if (e->xd == 1) {
-        if (e->r16) v7_engine_kernel<1, true, WRK_MAT_Q4_K><<<grid, block, lds, q>>>(A, e->wg_head);
-        else v7_engine_kernel<1, false, WRK_MAT_Q4_K><<<grid, block, lds, q>>>(A, e->wg_head);
-    } else {
-        if (e->r16) v7_engine_kernel<2, true, WRK_MAT_Q4_K><<<grid, block, lds, q>>>(A, e->wg_head);
-        else v7_engine_kernel<2, false, WRK_MAT_Q4_K><<<grid, block, lds, q>>>(A, e->wg_head);
-    }
+    const dim3 grid(e->S.nwg), block((e->ncw + 2) * 64);
+    hipLaunchKernelGGL(eng_kernel(e->xd, e->r16, e->ncw), grid, block, e->S.lds_total, q, A, (const uint32_t*)e->wg_head);
     WRK_LAUNCH_CHECK(ctx);
     return WRK_OK;
 }
@@ -996,34 +1083,55 @@ int32_t wrk_v7_engine_check(wrk_v7_engine* e) {
 void wrk_v7_engine_report(wrk_v7_engine* e) {
     using namespace wrk;
     if (!e || !e->stamps) return;
-    const uint32_t NWG = e->S.nwg;
-    std::vector<unsigned long long> h((size_t)NWG * 6 * ENG_STAMPS);
+    const uint32_t NWG = e->S.nwg, NW = (uint32_t)e->ncw + 2;
+    std::vector<unsigned long long> h((size_t)NWG * NW * 24);
     if (hipMemcpy(h.data(), e->stamps, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
     unsigned long long t0 = ~0ull;
     for (auto v : h) if (v && v < t0) t0 = v;
-    auto col = [&](uint32_t wave, uint32_t k, const char* label) {
+    // wave: which wave's stamp; -1 = the LAST compute wave of each workgroup to pass the point
+    auto col = [&](int wave, uint32_t k, const char* label) {
         std::vector<double> v;
-        for (uint32_t w = 0; w < NWG; ++w) { const auto x = h[((size_t)w * 6 + wave) * ENG_STAMPS + k]; if (x) v.push_back((double)(x - t0) * 0.01); }
+        for (uint32_t w = 0; w < NWG; ++w) {
+            unsigned long long x = 0;
+            if (wave >= 0) x = h[((size_t)w * NW + wave) * 24 + k];
+            else for (int cw = 0; cw < e->ncw; ++cw) x = std::max(x, h[((size_t)w * NW + cw) * 24 + k]);
+            if (x) v.push_back((double)(x - t0) * 0.01);
+        }
         if (v.empty()) return;
         std::sort(v.begin(), v.end());
-        fprintf(stderr, "  %-58s %4zu WGs  first %7.2f  median %7.2f  last %7.2f us\n", label, v.size(), v.front(), v[v.size() / 2], v.back());
+        fprintf(stderr, "  %-62s %4zu WGs  first %7.2f  median %7.2f  last %7.2f us\n", label, v.size(), v.front(), v[v.size() / 2], v.back());
     };
-    fprintf(stderr, "[WRK_TIMING] decode engine, one layer of the last token; us since the layer's first stamp\n");
-    col(4, 0, "gather: layer input complete");
-    col(0, 1, "K1 start (input + weights in LDS)");
-    col(0, 2, "K1 LN + shift done");
-    col(0, 3, "K1 rows published");
-    col(4, 1, "gather (heads): K1 outputs complete");
+    {
+        unsigned long long tail[2] = {0, 0};
+        if (hipMemcpy(tail, e->stamps + (size_t)NWG * 16 * 24, 16, hipMemcpyDeviceToHost) == hipSuccess && tail[1])
+            fprintf(stderr, "[WRK_TIMING] decode engine: shader clock over the last launch %.0f MHz (%llu cycles in %.1f us)\n",
+                    (double)tail[0] / ((double)tail[1] * 0.01), tail[0], (double)tail[1] * 0.01);
+    }
+    const int G = e->ncw, Ld = e->ncw + 1;
+    fprintf(stderr, "[WRK_TIMING] decode engine (%d compute waves), one layer of the last token; us since the layer's first stamp\n", e->ncw);
+    col(G, 0, "gather: layer input complete");
+    col(0, 1, "K1 start (input + weights in LDS), wave 0");
+    col(0, 2, "K1 LN + shift done, wave 0");
+    col(0, 3, "K1 rows published, wave 0");
+    col(-1, 3, "K1 rows published, slowest wave");
+    col(G, 1, "gather (heads): K1 outputs complete");
     col(0, 4, "K2 start");
+    col(-1, 16, "K2 LoRA dots done, slowest wave");
+    col(0, 17, "K2 per-channel stage done");
+    col(-1, 18, "K2 state updated, slowest wave");
     col(0, 5, "K2 published");
-    col(4, 2, "gather: head outputs complete");
+    col(G, 2, "gather: head outputs complete");
     col(0, 6, "K3 start");
-    col(0, 7, "K3 published");
-    col(4, 3, "gather: x1 complete");
+    col(-1, 7, "K3 published, slowest wave");
+    col(G, 3, "gather: x1 complete");
     col(0, 8, "K5 start");
-    col(0, 9, "K5 published");
-    col(4, 4, "gather: ffn vector complete");
-    col(0, 10, "K6 start");
-    col(0, 11, "K6 published");
-    col(5, 0, "loader: K1 slot free, next layer's fill issued");
+    col(0, 14, "K5 LN + shift done, wave 0");
+    col(0, 9, "K5 published, wave 0");
+    col(-1, 9, "K5 published, slowest wave");
+    col(0, 10, "K6 own quarter of the ffn vector swept, wave 0");
+    col(-1, 10, "K6 swept, slowest wave");
+    col(0, 11, "K6 start");
+    col(-1, 12, "K6 partial sums done, slowest wave");
+    col(0, 13, "K6 published");
+    col(Ld, 0, "loader: K1 slot free, next layer's fill issued");
 }
