@@ -245,3 +245,55 @@ def test_quantile_student_levels():
         assert np.allclose(got, want, rtol=1e-6, atol=1e-7), (nu, np.abs(got - want).max())
     with pytest.raises(wrk.WrkError):
         wrk.quantile_student(-1.0)
+
+
+# ------------------------------------------------------------------ INTEGRATION.md's Rust binding vs include/wrk_hip.h
+def _load_gen():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_rust_binding", os.path.join(ROOT, "tools", "gen_rust_binding.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_integration_rust_binding_matches_the_header():
+    """The `extern "C"` block a maintainer would paste into src/backend/hip.rs is generated from the header; the copy in INTEGRATION.md
+    must be that output, byte for byte."""
+    gen = _load_gen()
+    want = gen.generate(open(gen.HEADER).read())
+    got = gen.doc_block(open(gen.DOC).read())
+    assert got is not None, "INTEGRATION.md has no generated Rust block"
+    assert got == want, "INTEGRATION.md is stale: run `python tools/gen_rust_binding.py --write`"
+
+
+def test_integration_rust_binding_independent_check():
+    """Independent of the generator: parse the Rust block and the C header separately; every export is bound, with the same arity and
+    the same pointer / scalar kind and pointee per argument (a `*const WrkBuf` where the header takes `const wrk_tensor*` is UB)."""
+    import re
+    gen = _load_gen()
+    rust = gen.doc_block(open(gen.DOC).read())
+    hdr = re.sub(r"/\*.*?\*/", "", open(gen.HEADER).read(), flags=re.S)
+    hdr = re.sub(r"//[^\n]*", "", hdr)
+    cfun = {}
+    for m in re.finditer(r"^\s*([\w\s\*]+?)\s*\b(wrk_\w+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.M | re.S):
+        args = " ".join(m.group(3).split())
+        cfun[m.group(2)] = [] if args in ("", "void") else [a.strip() for a in args.split(",")]
+    rfun = {}
+    for m in re.finditer(r"pub fn (wrk_\w+)\((.*?)\)(?: -> [^;]+)?;", rust):
+        rfun[m.group(1)] = [a.split(":", 1)[1].strip() for a in m.group(2).split(",")] if m.group(2).strip() else []
+    assert set(cfun) == set(rfun), (sorted(set(cfun) - set(rfun)), sorted(set(rfun) - set(cfun)))
+    scal = {"int32_t": "i32", "uint32_t": "u32", "uint16_t": "u16", "size_t": "usize", "float": "f32", "void": "c_void", "char": "c_char", "int": "i32"}
+
+    def camel(c):
+        return "".join(p.capitalize() for p in c.split("_"))
+    for name, cargs in cfun.items():
+        rargs = rfun[name]
+        assert len(cargs) == len(rargs), name
+        for ca, ra in zip(cargs, rargs):
+            depth = ca.count("*")
+            base = re.sub(r"\bconst\b", "", ca).replace("*", " ").split()[0]
+            assert ra.count("*") == depth, (name, ca, ra)
+            pointee = ra.replace("*const", "").replace("*mut", "").strip()
+            assert pointee == (scal.get(base) or camel(base)), (name, ca, ra)
+            if depth == 1:
+                assert ra.startswith("*const") == bool(re.search(r"\bconst\b", ca)), (name, ca, ra)

@@ -542,6 +542,22 @@ __global__ void __launch_bounds__((NCW + 2) * 64) v7_engine_kernel(const EngArgs
             }
         }
 
+        // K5's LN operands are requested BEFORE K3 waits for its input, a stage and a hand-off before they are needed: requested at the end
+        // of K3 they shared this CU's memory pipeline with the gather wave's polls for x1 (that hand-off took 2.0 us, its siblings 1.0)
+        auto request_k5 = [&]() {
+            if (ln_wave) {
+                float* rowf = lst + (size_t)(srows - 1) * D;
+    #pragma unroll
+                for (int v = 0; v < VPT; ++v) {
+                    const uint32_t i = min(tid + 256u * v, nvec - 1);
+                    wv[v] = *(const f16x8*)(lvec(ENG_V_LN2W) + i * 8);
+                    bv[v] = *(const f16x8*)(lvec(ENG_V_LN2B) + i * 8);
+                    mv[v] = *(const f16x8*)(lvec(ENG_V_FFNXK) + i * 8);
+                    pv[v][0] = *(const f32x4*)(rowf + i * 8);
+                    pv[v][1] = *(const f32x4*)(rowf + i * 8 + 4);
+                }
+            }
+        };
         if (!is_head) {
             // ================================================ K1
             ENG_BAR();                                      // x in xraw0, K1 weights in their slot
@@ -703,6 +719,7 @@ __global__ void __launch_bounds__((NCW + 2) * 64) v7_engine_kernel(const EngArgs
         }
 
         // ================================================ K3: x1 = x + W_o . o
+        request_k5();                                       // in flight across the K2 -> K3 hand-off
         ENG_BAR();                                          // o in xs, W_o rows in their slot
         if (*abort_flag) break;
         ENG_STAMP0(l, 6);
@@ -713,19 +730,6 @@ __global__ void __launch_bounds__((NCW + 2) * 64) v7_engine_kernel(const EngArgs
             const uint32_t gb = S.g_x1;
             eng_rows<QK, R16, XD, 2>(smem + S.lds_slot3, S.rb_d, D, xs, k3_row0, rb, re, fin, A.gran, eng_tag(l, 2), [&](uint32_t r) { return gb + (r >> 1); },
                                      (f16*)nullptr, lane);
-        }
-        // requests of K5's prologue (the ffn shift state was last written by the previous token)
-        if (ln_wave) {
-            float* rowf = lst + (size_t)(srows - 1) * D;
-#pragma unroll
-            for (int v = 0; v < VPT; ++v) {
-                const uint32_t i = min(tid + 256u * v, nvec - 1);
-                wv[v] = *(const f16x8*)(lvec(ENG_V_LN2W) + i * 8);
-                bv[v] = *(const f16x8*)(lvec(ENG_V_LN2B) + i * 8);
-                mv[v] = *(const f16x8*)(lvec(ENG_V_FFNXK) + i * 8);
-                pv[v][0] = *(const f32x4*)(rowf + i * 8);
-                pv[v][1] = *(const f32x4*)(rowf + i * 8 + 4);
-            }
         }
         ENG_STAMP0(l, 7);
         ENG_BAR();                                          // K3 done
