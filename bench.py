@@ -265,6 +265,37 @@ def cpu_baseline(gguf_bytes, first_token, seconds=15.0):
     return cport.time_decode(gguf_bytes, first_token, seconds)
 
 
+MFMA_PEAK_TFLOPS = 2500.0   # dense f16 / bf16 MFMA peak of the chip (MI355X_MICROARCH.md; the 5 PF headline includes 2:1 sparsity)
+
+
+def prefill_leg(wrk, ctx, rt, model, batch, prompt, chunk, repeats=5, warmups=2, mode=1):
+    """The reference's prefill protocol (examples/bench.rs:176-222, bench_format.rs:34-35): `batch` prompts of `prompt` random tokens fed
+    through runtime.infer in chunks of `chunk` tokens (token_chunk_size), option Last; `warmups` untimed runs, then `repeats` timed ones
+    (wall clock around the whole prompt, logits read-back of the last row included, as the reference times it).  Reports the mean."""
+    L, D, F, V, lw, la, lv, lg = CONFIGS[model]
+    flop_tok = 2.0 * (12.0 * D * D * L + L * 2.0 * D * (lw + la + lg) + (L - 1) * 2.0 * D * lv)      # SURVEY 8(d): dense contraction per token
+    times = []
+    for rep in range(warmups + repeats):
+        toks = [[(7 + 13 * i + 101 * b + rep) % (V - 1) for i in range(prompt)] for b in range(batch)]
+        inp = wrk.RnnInput(toks, chunk)
+        ctx.sync()
+        t0 = time.perf_counter()
+        chunks = 0
+        while sum(inp.remaining(b) for b in range(batch)) > 0:
+            rt.infer(inp, mode=mode)
+            chunks += 1
+        ctx.sync()
+        if rep >= warmups:
+            times.append(time.perf_counter() - t0)
+    mean = sum(times) / len(times)
+    total = prompt * batch
+    tflops = total * flop_tok / mean / 1e12
+    return {"tokens": prompt, "streams": batch, "chunk": chunk, "chunks": chunks, "repeats": repeats, "warmups": warmups,
+            "tokens_per_s": round(total / mean, 1), "ms": round(mean * 1e3, 3), "ms_best": round(min(times) * 1e3, 3),
+            "matrix_tflops": round(tflops, 2), "peak_tflops": MFMA_PEAK_TFLOPS, "mfma_frac": round(tflops / MFMA_PEAK_TFLOPS, 4),
+            "protocol": "examples/bench.rs: random prompt, token_chunk_size chunks, wall clock incl. logits read-back of the last row"}
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -343,6 +374,7 @@ def main():
     ap.add_argument("--mode", type=int, default=1, help="1 = fused decode kernels, 0 = one kernel per reference op")
     ap.add_argument("--groups", type=int, default=1, help="deal the --batch streams of a GPU over this many concurrent decode pipelines (RWKV-7; 1 = one batched step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prefill", action="store_true", help="skip the prefill legs (pp512 of the reference's protocol, and 32 x 128 stacked tokens)")
     ap.add_argument("--quant", default="", help="ModelBuilder::quant map, e.g. int8:0-29,nf4:30-60 (layers inclusive)")
     ap.add_argument("--mixed", action="store_true", help="llama.cpp Q4_K_M tensor mix: Q6_K for attn value / ffn value in about half of the layers")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -473,12 +505,25 @@ def main():
                          "kernel": "one decode step = one hipGraph launch", "algorithmic_bytes_per_launch": token_bytes},
             "wall_ms_per_step_incl_host": round(wall_ms / args.steps, 5), "load_seconds": round(load_s, 1),
         }
+        # the reference's bench is pp512 + tg128 (examples/bench.rs:33,94-97): the decode above is the tg leg (headline metric); the prefill
+        # legs ride in the same line.  RWKV-7 models, one GPU, after the timed region.
+        if world == 1 and not args.no_prefill and args.model in CONFIGS:
+            try:
+                out["prefill"] = prefill_leg(wrk, ctx, runtime, args.model, 1, 512, 128, mode=args.mode)
+                runtime.close()
+                rt32 = wrk.Runtime(ctx, reader, num_batch=32, weights=wrk.WEIGHTS_INLINE, quant=quant or None)      # cfg-3 regime: 32 prompts stacked
+                out["prefill_batched"] = prefill_leg(wrk, ctx, rt32, args.model, 32, 128, 32 * 128, repeats=3, warmups=1, mode=args.mode)     # one chunk of 4096 stacked tokens
+                rt32.close()
+                runtime = None
+            except Exception as e:      # a failing extra leg must not take the headline line with it
+                out["prefill"] = out.get("prefill") or {"error": str(e)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(gg, first[0]) if args.model not in CONFIGS_V6 else None     # the C port is RWKV-7 only
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    runtime.close()
+    if runtime is not None:
+        runtime.close()
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -89,6 +89,8 @@ def test_engine_greedy_loop_and_layer_entry(ctx, monkeypatch):
         x = rng.standard_normal((1, D)).astype(np.float16)
         vf = rng.standard_normal((1, D)).astype(np.float16)
 
+        monkeypatch.setenv("WRK_ENGINE_INSPECT", "1")         # the layer entry point runs the launches (it serves frame read-back) unless told otherwise
+
         def layers(r):
             outs = []
             for layer, v in ((0, None), (2, vf)):

@@ -5,7 +5,6 @@ import socket
 import sys
 
 import pytest
-import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -36,6 +35,9 @@ def _worker(rank, world, port, q):
 
 
 def test_two_rank_replica_group():
+    # torch is imported HERE, not at module level: `pytest -m gpu` collects this module too, and a process that has loaded PyTorch's
+    # bundled HIP runtime before libwrk_hip.so runs the GPU tests on a mixed pair of runtimes
+    import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

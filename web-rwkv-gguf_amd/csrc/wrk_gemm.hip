@@ -31,6 +31,23 @@
 
 #include "wrk_device.h"
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE property of a kernel: set it once per (device, kernel), under a lock (contexts
+// on several GPUs, encoders on several threads) -- ADVICE r02: a process-wide `static bool done` left the second GPU's launch rejected.
+#include <mutex>
+#include <set>
+#include <utility>
+static bool lds_attr_once(const void* fn, size_t bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<int, const void*>> done;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.count({dev, fn})) return true;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return false;
+    done.insert({dev, fn});
+    return true;
+}
+
 namespace wrk {
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
@@ -1665,8 +1682,7 @@ static int launch_ks(hipStream_t s, const MatJob* jobs, int njobs, uint32_t n) {
 #define KS_LAUNCH(NT_, BPS_)                                                                                                              \
     do {                                                                                                                                  \
         if (smem > 64 * 1024) {                                                                                                           \
-            static bool done = false;                                                                                                     \
-            if (!done) { if (hipFuncSetAttribute((const void*)gemm_ks_kernel<NT_, BPS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -1; done = true; } \
+            if (!lds_attr_once((const void*)gemm_ks_kernel<NT_, BPS_>, smem)) return -1;                                                  \
         }                                                                                                                                 \
         gemm_ks_kernel<NT_, BPS_><<<dim3(wg), 256, smem, s>>>(B);                                                                         \
     } while (0)
@@ -1723,20 +1739,11 @@ int matmul_mfma_multi(hipStream_t s, const MatJob* jobs, int njobs, int) {
         // workgroup per CU, or spills at 256) -- more MFMAs per dequantised fragment buy nothing, the LDS fragment reads (1 KB per two
         // MFMAs) are the co-limiter; the gain is the unconditional loads and the shorter stages.
         const size_t smem2 = (size_t)2 * 64 * T2_ROW * sizeof(f16);       // 34 816 B
-        static bool done = false;
-        if (!done) {
-            if (hipFuncSetAttribute((const void*)gemm_tile2_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2) != hipSuccess) return -1;
-            done = true;
-        }
         gemm_tile2_kernel<4><<<dim3(t2wg, (n + 63) / 64), 256, smem2, s>>>(T2);
     }
     if (T.njobs) {
         const size_t smem = (size_t)2 * TILE_TOK * TILE_LDS_ROW * sizeof(f16);       // 67 584 B
-        static bool attr_set = false;
-        if (!attr_set) {
-            if (hipFuncSetAttribute((const void*)gemm_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -1;
-            attr_set = true;
-        }
+        if (!lds_attr_once((const void*)gemm_tile_kernel, smem)) return -1;
         gemm_tile_kernel<<<dim3(twg, (n + TILE_TOK - 1) / TILE_TOK), 256, smem, s>>>(T);
     }
     if (Dq.njobs) gemm_dec_kernel<<<dim3(dwg), 256, 0, s>>>(Dq);

@@ -73,6 +73,8 @@ struct wrk_v7_model {
     // persistent batch-1 decode engine (wrk_v7_engine.hip): built on first use, nullptr when the model / device does not fit it
     struct wrk_v7_engine* engine = nullptr;
     bool engine_tried = false;
+    bool engine_skip_once = false;      // wrk_v7_infer_layer: the frame buffers must be materialised -> launches (unless WRK_ENGINE_INSPECT=1)
+    bool engine_blocked = false;        // set while several pipelines share the GPU (generate_greedy with groups > 1)
     std::string engine_why;             // why the engine is not available (diagnostics)
     int32_t ensure_engine();            // outside captures; WRK_OK also when the engine is unavailable
     bool engine_on() const;             // WRK_ENGINE != 0 and the engine exists
@@ -88,7 +90,8 @@ struct wrk_v7_model {
 };
 
 int32_t wrk_buf_write_raw(wrk_ctx* ctx, void* dst, const void* src, size_t bytes);
-bool split_head_env_on();     // WRK_SPLIT_HEAD != 0, read per call (part of the graph keys)
+bool split_head_env_on();
+bool engine_env_on_public();  // WRK_ENGINE != 0, read per call     // WRK_SPLIT_HEAD != 0, read per call (part of the graph keys)
 
 namespace wrk {
 // tokens <- argmax; history[counter][b] = argmax[b]; counter += 1   (one tiny kernel)

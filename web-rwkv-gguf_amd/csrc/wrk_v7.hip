@@ -627,9 +627,12 @@ int32_t wrk_v7_infer_layer(wrk_ctx* ctx, wrk_v7_model* m, wrk_v7_state* st, uint
     if (rc == WRK_OK && v_first) rc = wrk_buf_write_raw(ctx, m->s.att_v0, v_first, (size_t)T * m->d.num_emb * esz);
     if (rc != WRK_OK) return rc;
     m->layer_begin = layer; m->layer_end = layer + 1; m->skip_embed = true;
+    // this entry point exists to read the frame buffers of a layer back (wrk_v7_frame_read): the engine keeps them in LDS and granules,
+    // so the launches run here; WRK_ENGINE_INSPECT=1 (tests/test_gpu_engine.py) runs the engine's layer instead
+    { const char* ei = getenv("WRK_ENGINE_INSPECT"); m->engine_skip_once = !(ei && ei[0] == '1'); }
     if (mode == 1 && one_token_each && nseq == T && m->act_dtype == WRK_F16) rc = m->enqueue_fused_decode(st, T, 0, true, false, false, false, cursors[0] & 0xff, contiguous);
     else rc = m->enqueue_ops(st, T, 0, true, mode == 1);
-    m->layer_begin = 0; m->layer_end = 0xffffffffu; m->skip_embed = false;
+    m->layer_begin = 0; m->layer_end = 0xffffffffu; m->skip_embed = false; m->engine_skip_once = false;
     if (rc != WRK_OK) return rc;
     WRK_LAUNCH_CHECK(ctx);
     WRK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -750,14 +753,27 @@ int32_t wrk_v7_generate_greedy(wrk_ctx* ctx, wrk_v7_model* m, wrk_v7_state* st, 
     std::vector<Lane> L(groups);
     for (uint32_t g = 0; g < groups; ++g) {
         L[g].mdl = g == 0 ? m : m->lanes[g - 1];
+        // the persistent engine needs every CU for itself: two of them side by side (one per lane) would each hold part of the chip
+        // and wait for the rest forever (until their bounded spins give up) -- concurrent pipelines keep the five-launch layer
+        L[g].mdl->engine_blocked = groups > 1;
         L[g].b0 = (uint32_t)((uint64_t)B * g / groups);
         L[g].nb = (uint32_t)((uint64_t)B * (g + 1) / groups) - L[g].b0;
         const int32_t rc = greedy_prepare(ctx, L[g].mdl, st, first_tokens + L[g].b0, L[g].b0, L[g].nb, steps, mode, eager, &L[g].prog);
         if (rc != WRK_OK) return rc;
     }
-    hipEvent_t e0, e1;
-    WRK_HIP(ctx, hipEventCreate(&e0));
-    WRK_HIP(ctx, hipEventCreate(&e1));
+    // every early return below leaves through this guard: the timing events are destroyed and, after an error, the lane streams are
+    // drained (a lane's queued step programs must not outlive a frame that the next call may reallocate) -- ADVICE r02
+    struct Guard {
+        wrk_v7_model* m; hipEvent_t e0 = nullptr, e1 = nullptr; bool ok = false;
+        ~Guard() {
+            if (!ok) { for (hipStream_t ls : m->lane_streams) hipStreamSynchronize(ls); hipStreamSynchronize(m->ctx->stream); }
+            if (e0) hipEventDestroy(e0);
+            if (e1) hipEventDestroy(e1);
+        }
+    } guard{m};
+    WRK_HIP(ctx, hipEventCreate(&guard.e0));
+    WRK_HIP(ctx, hipEventCreate(&guard.e1));
+    hipEvent_t e0 = guard.e0, e1 = guard.e1;
     WRK_HIP(ctx, hipEventRecord(e0, ctx->stream));
     if (groups == 1) {
         for (uint32_t i = 0; i < steps; ++i) {
@@ -790,8 +806,6 @@ int32_t wrk_v7_generate_greedy(wrk_ctx* ctx, wrk_v7_model* m, wrk_v7_state* st, 
     WRK_HIP(ctx, hipEventSynchronize(e1));
     float ms = 0.0f;
     WRK_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
     if (elapsed_ms) *elapsed_ms = ms;
     for (uint32_t g = 0; g < groups; ++g) {
         const Lane& ln = L[g];
@@ -809,6 +823,7 @@ int32_t wrk_v7_generate_greedy(wrk_ctx* ctx, wrk_v7_model* m, wrk_v7_state* st, 
         const int32_t rc = wrk_v7_engine_check(L[g].mdl->engine);
         if (rc != WRK_OK) return rc;
     }
+    guard.ok = true;
     return WRK_OK;
 }
 
@@ -817,7 +832,8 @@ int32_t wrk_v7_generate_greedy(wrk_ctx* ctx, wrk_v7_model* m, wrk_v7_state* st, 
 // Persistent decode engine: built once, outside captures.  WRK_ENGINE=0 keeps the five-launch layer (read per call, part of the
 // graph key: tests compare the two paths in one process).
 static bool engine_env_on() { const char* e = getenv("WRK_ENGINE"); return !(e && e[0] == '0'); }
-bool wrk_v7_model::engine_on() const { return engine != nullptr && engine_env_on() && act_dtype == WRK_F16; }
+bool engine_env_on_public() { return engine_env_on(); }
+bool wrk_v7_model::engine_on() const { return engine != nullptr && !engine_blocked && engine_env_on() && act_dtype == WRK_F16; }
 int32_t wrk_v7_model::ensure_engine() {
     if (engine_tried || !engine_env_on() || act_dtype != WRK_F16) return WRK_OK;
     if (ctx->capturing_here()) return WRK_OK;       // allocations are not capturable: the caller's program keeps the launches

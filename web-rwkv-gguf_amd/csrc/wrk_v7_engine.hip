@@ -387,10 +387,11 @@ __global__ void __launch_bounds__((NCW + 2) * 64) v7_engine_kernel(const EngArgs
         auto fill3 = [&](uint32_t l) { const EngLayer& L = A.layers[l]; issued += eng_fill(L.w_o + (size_t)k3_row0 * S.rb_d, k3_rows * S.rb_d, smem, S.lds_slot3, lane); m3 = issued; };
         auto fill5 = [&](uint32_t l) { const EngLayer& L = A.layers[l]; issued += eng_fill(L.ffn_k + (size_t)k5_row0 * S.rb_d, k5_rows * S.rb_d, smem, S.lds_slot5, lane); m5 = issued; };
         auto fill6 = [&](uint32_t l) { const EngLayer& L = A.layers[l]; issued += eng_fill(L.ffn_v + (size_t)k6_row0 * S.rb_f, k6_rows * S.rb_f, smem, S.lds_slot6, lane); m6 = issued; };
-        fill1(S.layer_begin); fill3(S.layer_begin); fill5(S.layer_begin); fill6(S.layer_begin);
-        // A slot is refilled (for the next layer) one barrier AFTER its stage has ended: behind the first barrier of the following stage,
-        // i.e. when that stage's gather is over -- a 37-piece DMA burst issued at the stage's end queued in this CU's memory pipeline
-        // right in front of the gather wave's polls (timeline of the first build: 2.7 us for a hand-off that takes 1 us).
+        // WHEN a slot's DMA burst goes out matters: it sits in this CU's memory pipeline in front of the gather wave's polls.  Measured
+        // schedules (1.5B, ms per token, launches 0.613): at the end of the slot's stage 0.628; one barrier later, i.e. when the next
+        // stage's gather is over (this one) 0.604 - 0.608; every burst between the end of K1 and K3's gather 0.616 (the head workgroups'
+        // K3 slot then lands late); a trickle of 6 / 10 pieces behind every barrier 0.79 / 0.73 (the loader arrives late at the LN
+        // barriers).  profiles/r03_engine_ab.txt.
         uint32_t pending = 0;                               // 1, 3, 5, 6: slot whose stage has just ended; 0 none
         auto refill = [&](uint32_t l) {
             if (pending == 1) fill1(l + 1);
@@ -399,6 +400,7 @@ __global__ void __launch_bounds__((NCW + 2) * 64) v7_engine_kernel(const EngArgs
             else if (pending == 6) fill6(l);                // issued inside the next layer's K1: `l` is already the next layer
             pending = 0;
         };
+        fill1(S.layer_begin); fill3(S.layer_begin); fill5(S.layer_begin); fill6(S.layer_begin);
         for (uint32_t l = S.layer_begin; l < S.layer_end; ++l) {
             const bool more = l + 1 < S.layer_end;
             // K1
@@ -1035,10 +1037,24 @@ int32_t wrk_v7_engine_create(wrk_v7_model* m, wrk_v7_engine** out) {
         wrk_v7_engine_destroy(e);
         return wrk_fail(ctx, WRK_E_UNSUPPORTED, "decode engine: %u bytes of LDS refused (%s)", S.lds_total, hipGetErrorString(er));
     }
-    // one workgroup per CU, all resident
-    int per_cu = 0;
-    er = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, (e->ncw + 2) * 64, S.lds_total);
-    if (er != hipSuccess || per_cu < 1) { wrk_v7_engine_destroy(e); return no("the kernel is not resident with this much LDS"); }
+    // One workgroup per CU, all of them resident at once.  Checked from the kernel's own resource figures, not with
+    // hipOccupancyMaxActiveBlocksPerMultiprocessor: in a process that has ALSO loaded PyTorch's bundled HIP runtime (the test suite imports
+    // torch for its gloo tests; bench.py --gpus N for the timing barrier) that call answered 0 blocks without an error for this kernel,
+    // while the launches themselves work -- round 3, GPU test run.
+    {
+        hipFuncAttributes fa{};
+        const int waves = e->ncw + 2, per_simd = (waves + 3) / 4;
+        if (hipFuncGetAttributes(&fa, fn) == hipSuccess && fa.numRegs > 0) {
+            const int alloc = (fa.numRegs + 7) / 8 * 8;
+            if (per_simd * alloc > 512 || fa.maxThreadsPerBlock < waves * 64 || (size_t)fa.sharedSizeBytes + S.lds_total > 160 * 1024) {
+                const int regs = fa.numRegs;
+                wrk_v7_engine_destroy(e);
+                return wrk_fail(ctx, WRK_E_UNSUPPORTED, "decode engine: a workgroup of %d waves x %d registers + %u bytes of LDS does not fit a CU", waves, regs,
+                                S.lds_total);
+            }
+        }
+        (void)hipGetLastError();
+    }
     *out = e;
     return WRK_OK;
 }

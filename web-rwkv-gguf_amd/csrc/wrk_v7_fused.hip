@@ -555,6 +555,9 @@ int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_
         if (ln_mix(q, P, n) != 0) return wrk_fail(ctx, WRK_E_UNSUPPORTED, "ln_mix shape");   \
     } while (0)
 
+    // the K-sliced GEMM's arrival counters must be zero when a step starts; its kernels leave them zero, but a launch that faulted or was
+    // aborted would poison every later replay of this frame -- so the step program zeroes them first (a memset node, ~1 KB)
+    if (T >= 2 && s.ks_cnt && s.ks_cnt_cap) WRK_HIP(ctx, hipMemsetAsync(s.ks_cnt, 0, (size_t)s.ks_cnt_cap * 4, q));
     // embed: gather (device table) + LN(ln0) -> x   (v7.rs:438-474, 649-659)
     if (!skip_embed) {
         LnMixParams P{};
@@ -566,7 +569,7 @@ int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_
     }
     // one sequence, one token: the persistent engine takes every layer of the step in ONE launch (wrk_v7_engine.hip)
     uint32_t first_launch_layer = layer_begin;
-    if (T == 1 && engine_on()) {
+    if (T == 1 && engine_on() && !engine_skip_once) {
         const uint32_t l1 = std::min<uint32_t>(d.num_layer, layer_end);
         if (layer_begin < l1) {
             const int32_t rc = wrk_v7_engine_enqueue(engine, q, st, cursor0_batch, layer_begin, l1, s.x, s.x, s.att_v0);
@@ -599,7 +602,10 @@ int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_
                      matvec(q, &k6, 1, ctx->num_cu, true) == 0;
         }
         // split head (4 workgroups per head, group norm in W_o's prologue): batch-1 decode whose W_o launch the dmv kernels take
-        const bool want_split = split_head_env_on();
+        // (a model that has the persistent engine computes one-token jobs with ONE workgroup per head there; wherever such a job falls back
+        // to the launches -- concurrent pipelines -- it keeps that arithmetic, so that the results do not depend on which of the two ran;
+        // the layer inspection entry point keeps the split head, whose hand-over buffers its callers read)
+        const bool want_split = split_head_env_on() && !(T == 1 && engine != nullptr && engine_env_on_public() && !engine_skip_once);
         const uint32_t state_stride = (S + 2) * D;       // floats between the state rows of consecutive sequences
         bool split_head = want_split && single && d.lora_w >= 8 && d.lora_a >= 8 && d.lora_g >= 8 && d.lora_v >= 8 && d.lora_g <= 512;
         if (split_head) {
