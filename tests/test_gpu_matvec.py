@@ -139,6 +139,9 @@ def test_gemm_activation_residual_f16_out_and_vec_agreement(ctx):
     ("F16", 2048, 96, 128), ("F16", 2560, 320, 70), ("F16", 2048, 64, 48),       # LoRA down-projections: tiled whatever their tile count
     # >= 512 tokens, Q4_K / Q5_K, rows in fours: the second-generation tile kernel (half-block stages), ragged row and token tails
     ("Q4_K", 2048, 520, 600), ("Q5_K", 1024, 1028, 530), ("Q4_K", 256, 2052, 640), ("Q4_K", 4096, 1100, 520), ("Q5_K", 2560, 260, 1030),
+    # Q4_K with >= 512 tokens: the third-generation tile (wrk_gemm3.hip: shared LDS A-tile, min term over sub-block input sums); 2560 = ten
+    # blocks: a last group of two; 8192: the ffn value shape
+    ("Q4_K", 2560, 260, 530), ("Q4_K", 8192, 132, 515), ("Q4_K", 1280, 128, 512),
     ("Q8_0", 2048, 520, 600), ("Q8_0", 1024, 1028, 530), ("Q8_0", 4096, 1100, 520), ("Q8_0", 128, 2052, 640),         # Q8_0: that kernel only
     ("F16", 2048, 96, 600), ("F16", 2560, 320, 530), ("F16", 256, 2052, 640), ("F16", 1024, 520, 1030)])      # F16 with K % 128 == 0
 def test_gemm_prefill_tile_kernel(ctx, kind, k, m, T):

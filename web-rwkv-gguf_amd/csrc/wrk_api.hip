@@ -39,6 +39,7 @@ int32_t wrk_ctx_destroy(wrk_ctx* ctx) {
     hipStreamSynchronize(ctx->stream);
     hipStreamSynchronize(ctx->read_stream);
     if (ctx->staging) hipHostFree(ctx->staging);
+    if (ctx->gemm_scratch) hipFree(ctx->gemm_scratch);
     for (auto& kv : ctx->sessions) { hipGraph_t g = nullptr; hipStreamEndCapture(kv.second, &g); if (g) hipGraphDestroy(g); hipStreamDestroy(kv.second); }
     for (hipStream_t s : ctx->capture_pool) hipStreamDestroy(s);
     hipEventDestroy(ctx->read_event);
@@ -47,6 +48,22 @@ int32_t wrk_ctx_destroy(wrk_ctx* ctx) {
     delete ctx;
     return WRK_OK;
 }
+
+}  // extern "C"
+
+int32_t wrk_ctx_reserve_gemm_scratch(wrk_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->gemm_scratch_cap) return WRK_OK;
+    if (ctx->capturing_here()) return WRK_OK;
+    WRK_HIP(ctx, hipStreamSynchronize(ctx->stream));        // programs in flight may still read the old buffer
+    void* p = nullptr;
+    WRK_HIP(ctx, hipMalloc(&p, bytes));
+    if (ctx->gemm_scratch) hipFree(ctx->gemm_scratch);
+    ctx->gemm_scratch = p;
+    ctx->gemm_scratch_cap = bytes;
+    return WRK_OK;
+}
+
+extern "C" {
 
 const char* wrk_last_error(wrk_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
@@ -414,6 +431,11 @@ int32_t wrk_op_matmul(wrk_ctx* ctx, const wrk_matrix* mat, const wrk_tensor* inp
     j.scale = mat->out_scale;
     int rc = -2;
     const size_t ntok = (size_t)input->view.shape[1] * input->view.shape[2];
+    if (turbo && ntok >= 512 && mat->kind == WRK_MAT_Q4_K) {                             // the third-generation prefill tile wants its sum scratch
+        const int32_t rs = wrk_ctx_reserve_gemm_scratch(ctx, ntok * (mat->k >> 5) * 4 + 1024);
+        if (rs != WRK_OK) return rs;
+    }
+    j.xsum = ctx->gemm_scratch; j.xsum_cap = ctx->gemm_scratch_cap;
     if (turbo && ntok >= 2) rc = wrk::matmul_mfma(ctx->op_stream(), j, ctx->num_cu);     // tiles are padded to 16 tokens
     if (rc == -2) rc = wrk::matvec(ctx->op_stream(), &j, 1, ctx->num_cu);
     WRK_ARG(ctx, rc == 0, "matmul: launch configuration rejected");

@@ -31,76 +31,9 @@
 
 #include "wrk_device.h"
 
-// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE property of a kernel: set it once per (device, kernel), under a lock (contexts
-// on several GPUs, encoders on several threads) -- ADVICE r02: a process-wide `static bool done` left the second GPU's launch rejected.
-#include <mutex>
-#include <set>
-#include <utility>
-static bool lds_attr_once(const void* fn, size_t bytes) {
-    static std::mutex mu;
-    static std::set<std::pair<int, const void*>> done;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return false;
-    std::lock_guard<std::mutex> lk(mu);
-    if (done.count({dev, fn})) return true;
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return false;
-    done.insert({dev, fn});
-    return true;
-}
+#include "wrk_gemm_dev.h"
 
 namespace wrk {
-
-typedef float f32x4v __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ f16x2 pk_bits(uint32_t v) { return __builtin_bit_cast(f16x2, v); }
-__device__ __forceinline__ f16x2 splat(float a) { f16x2 r = {(f16)a, (f16)a}; return r; }
-
-// 8 bytes (two dwords, each byte a code < 1024) -> f16x8 of subnormals code * 2^-24
-__device__ __forceinline__ f16x8 codes8(uint32_t w0, uint32_t w1) {
-    const f16x2 a = pk_bits(__builtin_amdgcn_perm(0u, w0, 0x0c010c00u)), b = pk_bits(__builtin_amdgcn_perm(0u, w0, 0x0c030c02u));
-    const f16x2 c = pk_bits(__builtin_amdgcn_perm(0u, w1, 0x0c010c00u)), d = pk_bits(__builtin_amdgcn_perm(0u, w1, 0x0c030c02u));
-    f16x8 r = {a[0], a[1], b[0], b[1], c[0], c[1], d[0], d[1]};
-    return r;
-}
-
-__device__ __forceinline__ f16x8 mul8(f16x8 v, float s) {
-    const f16 h = (f16)s;
-    f16x8 m = {h, h, h, h, h, h, h, h};
-    return v * m;
-}
-__device__ __forceinline__ f16x8 add8(f16x8 v, float s) {
-    const f16 h = (f16)s;
-    f16x8 m = {h, h, h, h, h, h, h, h};
-    return v + m;
-}
-
-__device__ __forceinline__ f32x4v mfma16(f16x8 a, f16x8 b, f32x4v c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
-}
-
-struct GemmParams {
-    const uint8_t* w;
-    uint32_t kind, k, m, row_bytes, act;
-    uint32_t n;                 // tokens
-    uint32_t has_res;
-    uint32_t wg_begin;          // first workgroup (in x) of this job
-    float scale;                // wrk_matrix::out_scale
-    unsigned long long* dbg;    // WRK_TIMING build: stamps of this launch
-    DTensor in, out, res;       // [K, T, B], [M, T, B]   (the LDS-tile kernels address through these)
-    // dense token stacks for the K-split kernel: token tok at base + tok * stride (elements)
-    const f16* x; const void* res_p; void* out_p;
-    uint32_t xs, rs, os, out32, res32;
-    const float* levels;        // NF4 / SF4: the 16 f32 levels (device)
-};
-
-constexpr int GEMM_MAX_JOBS = 8;
-struct GemmBatch {
-    GemmParams jobs[GEMM_MAX_JOBS];
-    int njobs;
-};
-
-// token index -> (t, b) of the [C, T, B] views
-__device__ __forceinline__ void tok_tb(const DTensor& d, uint32_t tok, uint32_t& t, uint32_t& b) { t = tok % d.shape[1]; b = tok / d.shape[1]; }
 
 // Residual operands of the C elements a lane stores: raw bits, requested with the first loads of the kernel.  UNCONDITIONAL: a launch
 // without residual (or with the other element type) reads a mapped dummy (the first activations).  The branchy form
@@ -1704,12 +1637,21 @@ int matmul_mfma_multi(hipStream_t s, const MatJob* jobs, int njobs, int) {
     // measured (round 1): SLOWER than the K-split kernel -- 12.2 vs 8.9 us for 8192 x 2048 x 16 tokens, batch-16 decode 2.35 vs
     // 1.76 ms -- 128 workgroups leave half the CUs idle and every 256-block costs a workgroup barrier.  Off unless WRK_GEMM_DEC=1.
     static const bool use_dec = [] { const char* e = getenv("WRK_GEMM_DEC"); return e && e[0] == '1'; }();
-    GemmBatch T, B, Dq, T2;
-    T.njobs = B.njobs = Dq.njobs = T2.njobs = 0;
-    uint32_t twg = 0, wg = 0, kmax = 0, dwg = 0, t2wg = 0;
+    GemmBatch T, B, Dq, T2, T3;
+    T.njobs = B.njobs = Dq.njobs = T2.njobs = T3.njobs = 0;
+    uint32_t twg = 0, wg = 0, kmax = 0, dwg = 0, t2wg = 0, t3wg = 0;
+    // third-generation prefill tile (wrk_gemm3.hip): Q4_K, >= 512 stacked tokens, the launch's sum scratch at hand.  WRK_GEMM_TILE3=0: off
+    // (read per call: the tests compare the kernels)
+    const char* t3e = getenv("WRK_GEMM_TILE3");
+    const bool use_tile3 = !(t3e && t3e[0] == '0') && jobs[0].xsum != nullptr && n >= 512;
     static const bool use_tile2 = [] { const char* e = getenv("WRK_GEMM_TILE2"); return !(e && e[0] == '0'); }();
     for (int q = 0; q < njobs; ++q) {
         const MatJob& j = jobs[q];
+        if (use_tile3 && j.kind == WRK_MAT_Q4_K && j.m >= 128 && j.in.shape[2] == 1 && (j.k & 255u) == 0 && T3.njobs < GEMM_MAX_JOBS) {
+            fill_job(T3.jobs[T3.njobs++], j, n, t3wg);
+            t3wg += (j.m + 127) / 128;
+            continue;
+        }
         // decode batches (<= 16 tokens): rows up to 24 blocks long go to the 64-row LDS tile; longer rows keep the K split
         if (use_dec && n <= 16 && (j.kind == WRK_MAT_Q4_K || j.kind == WRK_MAT_Q5_K) && j.m >= 64 && j.in.shape[2] == 1 && (j.k >> 8) <= 24) {
             fill_job(Dq.jobs[Dq.njobs++], j, n, dwg);
@@ -1732,6 +1674,10 @@ int matmul_mfma_multi(hipStream_t s, const MatJob* jobs, int njobs, int) {
         if (tile && use_tile2 && n >= 512 && (j.kind == WRK_MAT_Q4_K || j.kind == WRK_MAT_Q5_K || q8_tile2 || f16_tile2) && (j.m & 3u) == 0) { fill_job(T2.jobs[T2.njobs++], j, n, t2wg); t2wg += (j.m + TILE_ROWS - 1) / TILE_ROWS; }
         else if (tile) { fill_job(T.jobs[T.njobs++], j, n, twg); twg += (j.m + TILE_ROWS - 1) / TILE_ROWS; }
         else { fill_job(B.jobs[B.njobs++], j, n, wg); wg += (j.m + 15) / 16; kmax = j.k > kmax ? j.k : kmax; }
+    }
+    if (T3.njobs && gemm_tile3_launch(s, T3, t3wg, n, jobs[0].xsum, jobs[0].xsum_cap) != 0) {
+        // (scratch too small for this launch: the second-generation tile takes the jobs)
+        for (int q = 0; q < T3.njobs; ++q) { T2.jobs[T2.njobs] = T3.jobs[q]; T2.jobs[T2.njobs].wg_begin = t2wg; t2wg += (T3.jobs[q].m + TILE_ROWS - 1) / TILE_ROWS; ++T2.njobs; }
     }
     if (T2.njobs) {
         // 64-token tiles (TT = 4).  Measured on MI355X (round 2, 32 x 128-token prefill, tokens/s, 1.5B | 2.9B): first-generation tile

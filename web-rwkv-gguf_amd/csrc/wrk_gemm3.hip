@@ -1,0 +1,298 @@
+// Third-generation prefill tile GEMM for gfx950 (round 3): Y[M, N] = act(W[M, K] . X[K, N]) for Q4_K matrices and >= 512 stacked tokens.
+//
+// Replaces matmul_mat_q4k(_opt) (ops.rs:1332-1536, shaders/matmul_mat_q4k_opt.wgsl:86-229: 32 x 32 tile, f32 FMA).  Semantics: gguf.rs:95-143.
+//
+// What bounded the second-generation tile (wrk_gemm.hip gemm_tile2_kernel; 36.5 % matrix-pipe busy, HALF of it min-term MFMAs, 10 % of the
+// dense f16 peak end to end -- profiles/r02_prefill_mfma_util.json):
+//   * every wave dequantised its own 16 rows and fed each fragment to only 4 token tiles: 1 KB of LDS fragment reads per two MFMAs and
+//     ~20 vector instructions of unpacking per 4 useful MFMAs;
+//   * the K-quant min term  -dmin * m_s * sum_k x_k  rode the matrix core as a second MFMA per step (A = m_s splat).
+// Here:
+//   * a workgroup of 8 waves owns 128 rows x 128 tokens.  Each wave dequantises ONE 16-row tile per half block into an LDS A-tile that all
+//     eight waves read; a wave multiplies 64 rows x 32 tokens (4 x 2 register blocking): per 32-k step 4 A + 2 B fragment reads feed 8 MFMAs
+//     (0.75 reads per MFMA instead of 2), and the unpacking is done once per weight instead of once per token tile;
+//   * the min term is ONE small GEMM over the sub-block input sums: S[tok][s] = sum of the 32 inputs of sub-block s (a pre-pass over X,
+//     xsum_kernel, f32 split into hi + lo f16), A_min[row][s] = -dmin * m_s (17 significant bits: exact as hi + lo f16), and
+//     total += A_min . S as three MFMAs (hi.hi, hi.lo, lo.hi) per 1024 k and C tile: +9 % MFMAs instead of +100 %;
+//   * the main term is unchanged in value: A = q * sc (exact small integers in f16), accumulated per 256-block, total += d * acc in f32.
+// LDS: A 2 x 128 x 136 f16 + X 2 x 128 x 136 f16 + per-row d 2 x 128 f32 + A_min hi / lo 2 x 128 x 40 f16 = 157 KB: one workgroup (16 waves would
+// not fit the registers: 64 accumulator registers per wave) per CU, two waves per SIMD.
+#include <cstdlib>
+
+#include "wrk_gemm_dev.h"
+
+namespace wrk {
+
+constexpr int T3_ROWS = 128, T3_TOK = 128, T3_KH = 128, T3_LR = T3_KH + 8, T3_MR = 32 + 8;
+constexpr size_t T3_LDS = (size_t)(2 * 128 * T3_LR + 2 * 128 * T3_LR) * 2 + 2 * 128 * 4 + (size_t)2 * 128 * T3_MR * 2;
+
+struct T3Batch {
+    GemmBatch g;
+    const f16* sh[GEMM_MAX_JOBS];       // input sums, high parts: [token][K / 32]
+    const f16* sl[GEMM_MAX_JOBS];       // low parts
+};
+
+// sums of the 32 inputs of every sub-block, f32, stored as hi + lo f16 (hi = round(s), lo = round(s - hi): 22 significant bits)
+__global__ void __launch_bounds__(256) xsum_kernel(const f16* __restrict__ x, uint32_t xs, uint32_t n, uint32_t nsub, f16* __restrict__ sh, f16* __restrict__ sl) {
+    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= n * nsub) return;
+    const uint32_t tok = idx / nsub, sub = idx - tok * nsub;
+    const f16x8* p = (const f16x8*)(x + (size_t)tok * xs + sub * 32u);
+    const f16x2 one = {(f16)1.0f, (f16)1.0f};
+    float s = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f16x8 v = p[q];
+        s = __builtin_amdgcn_fdot2(__builtin_shufflevector(v, v, 0, 1), one, s, false);
+        s = __builtin_amdgcn_fdot2(__builtin_shufflevector(v, v, 2, 3), one, s, false);
+        s = __builtin_amdgcn_fdot2(__builtin_shufflevector(v, v, 4, 5), one, s, false);
+        s = __builtin_amdgcn_fdot2(__builtin_shufflevector(v, v, 6, 7), one, s, false);
+    }
+    const f16 h = (f16)s;
+    sh[idx] = h;
+    sl[idx] = (f16)(s - (float)h);
+}
+
+struct T3W { u32x2 q[4]; u32x4 sm; uint32_t dd; };
+
+// Dequantise half HF (k = 128 HF .. +127) of block b of ONE 16-row tile (rows 16 * tile + r of the workgroup: a wave's own tile) into the A buffer; with
+// HF == 0 also the row's d and the block's min products.
+template <int HF>
+__device__ __forceinline__ void t3_dequant(const T3W& R, uint32_t b, uint32_t nb, f16* __restrict__ As, float* __restrict__ Dd, f16* __restrict__ Amh,
+                                           f16* __restrict__ Aml, uint32_t tile, uint32_t r, uint32_t g) {
+    f16* arow = As + (16u * tile + r) * T3_LR + 8u * g;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const int j = 2 * HF + jj;
+        const u32x2 q = R.q[j];
+        const uint32_t v = R.sm[j];
+        const float sc0 = (float)(v & 0xffu), sc1 = (float)((v >> 8) & 0xffu);
+        *(f16x8*)(arow + jj * 64) = mul8(codes8(q.x & 0x0f0f0f0fu, q.y & 0x0f0f0f0fu), sc0 * 1024.0f);          // q * sc * 2^-14, exact
+        *(f16x8*)(arow + jj * 64 + 32) = mul8(codes8(q.x & 0xf0f0f0f0u, q.y & 0xf0f0f0f0u), sc1 * 64.0f);
+    }
+    if (HF == 0) {
+        const float d = (float)__builtin_bit_cast(f16, (uint16_t)(R.dd & 0xffffu)) * 16384.0f;
+        const float dmin = (float)__builtin_bit_cast(f16, (uint16_t)(R.dd >> 16));
+        if (g == 0) Dd[(b & 1u) * 128u + 16u * tile + r] = d;
+        // lane g: sub-blocks 2g, 2g + 1 of the block (the mins of 64-element group g)
+        const uint32_t v = g == 0 ? R.sm[0] : g == 1 ? R.sm[1] : g == 2 ? R.sm[2] : R.sm[3];
+        const float p0 = -(dmin * (float)((v >> 16) & 0xffu)), p1 = -(dmin * (float)(v >> 24));
+        const f16 h0 = (f16)p0, h1 = (f16)p1;
+        const f16x2 hh = {h0, h1}, ll = {(f16)(p0 - (float)h0), (f16)(p1 - (float)h1)};
+        const uint32_t col = (b & 3u) * 8u + 2u * g, rowo = (16u * tile + r) * T3_MR;
+        *(f16x2*)(Amh + rowo + col) = hh;
+        *(f16x2*)(Aml + rowo + col) = ll;
+        if (b + 1 == nb) {                      // last block: the rest of its group of four multiplies zeros
+            const f16x2 z = {(f16)0.0f, (f16)0.0f};
+            for (uint32_t bb = (b & 3u) + 1; bb < 4; ++bb) { *(f16x2*)(Amh + rowo + bb * 8u + 2u * g) = z; *(f16x2*)(Aml + rowo + bb * 8u + 2u * g) = z; }
+        }
+    }
+}
+
+// (A second build gave the waves ROLES -- waves 0-3 multiply 64 x 64 each, waves 4-7 only load / unpack / store the next half -- so that a
+// SIMD's matrix pipe and its vector pipe would be busy at the same time.  It was SLOWER: 304 vs 215 us per launch.  What bounds this kernel is
+// not the split of the issue slots but what a CU can take in: 41 KB of activations + weights per 128-k half per CU for 4.2 MFLOP, and the
+// eight waves keep only ~64 KB of loads in flight against ~2 us of latency under load = ~18 GB/s per CU (the second-generation tile, with
+// three workgroups per CU, takes in 28 GB/s per CU at half the arithmetic intensity).  See DESIGN.md 4.2.)
+template <int DIAG>     // 0: product; diagnostics (WRK_T3_DIAG, wrong results): 1 no activation loads, 2 no weight loads / unpacking, 3 no MFMA
+__global__ void __launch_bounds__(512) gemm_tile3_kernel(const T3Batch B) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char t3_smem[];
+    int ji = 0;
+#pragma unroll
+    for (int q = 1; q < GEMM_MAX_JOBS; ++q)
+        if (q < B.g.njobs && blockIdx.x >= B.g.jobs[q].wg_begin) ji = q;
+    const GemmParams& P = B.g.jobs[ji];
+    const f16* __restrict__ SH = B.sh[ji];
+    const f16* __restrict__ SL = B.sl[ji];
+    f16* As = (f16*)t3_smem;
+    f16* Xs = As + 2 * 128 * T3_LR;
+    float* Dd = (float*)(Xs + 2 * 128 * T3_LR);
+    f16* Amh = (f16*)(Dd + 256);
+    f16* Aml = Amh + 128 * T3_MR;
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const uint32_t r = lane & 15, g = lane >> 4, wy = wave >> 2, wx = wave & 3u;
+    const uint32_t m0 = (blockIdx.x - P.wg_begin) * T3_ROWS, n0 = blockIdx.y * T3_TOK;
+    const uint32_t K = P.k, nb = K >> 8, nsub = K >> 5;
+    // dequant role: rows m0 + 16 wave + r
+    const uint8_t* wrow = P.w + (size_t)min(m0 + 16u * wave + r, P.m - 1) * P.row_bytes;
+    const uint32_t hoff = nb * 128, soff = hoff + nb * 4;
+    auto load_w = [&](T3W& R, uint32_t b0) {
+        const uint32_t b = min(b0, nb - 1);
+        if (DIAG == 2) { for (int j = 0; j < 4; ++j) R.q[j] = (u32x2){b0, b0}; R.sm = (u32x4){1, 1, 1, 1}; R.dd = 1; return; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) R.q[j] = *(const u32x2*)(wrow + (size_t)b * 128 + j * 32 + 8 * g);
+        R.sm = *(const u32x4*)(wrow + soff + (size_t)b * 16);
+        R.dd = *(const uint32_t*)(wrow + hoff + (size_t)b * 4);
+    };
+    // activation staging: 128 tokens x 16 chunks of 8 f16 per half block; chunk c of a thread -> token (tid >> 4) + 32 c, columns 8 (tid & 15)
+    const f16* xsrc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) xsrc[c] = P.x + (size_t)min(n0 + (tid >> 4) + 32u * c, P.n - 1) * P.xs + (tid & 15u) * 8;
+    // the activations of a half are requested TWO halves before they are multiplied (one workgroup per CU: nothing else hides a global
+    // load's ~2 us under load)
+    f16x8 stage0[4], stage1[4];
+    const uint32_t nhalf = 2 * nb;
+    auto fetch_x = [&](f16x8 (&stage)[4], uint32_t h) {
+        const uint32_t hc = min(h, nhalf - 1);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) stage[c] = DIAG == 1 ? (f16x8){1, 1, 1, 1, 1, 1, 1, 1} : *(const f16x8*)(xsrc[c] + (size_t)hc * T3_KH);
+    };
+    auto store_x = [&](const f16x8 (&stage)[4], uint32_t buf) {
+        f16* base = Xs + (size_t)buf * 128 * T3_LR;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) *(f16x8*)(base + ((tid >> 4) + 32u * c) * T3_LR + (tid & 15u) * 8) = stage[c];
+    };
+
+    f32x4v total[4][2], acc[4][2];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) { total[rt][tt] = (f32x4v){0.f, 0.f, 0.f, 0.f}; acc[rt][tt] = (f32x4v){0.f, 0.f, 0.f, 0.f}; }
+    // input sums of this lane's tokens for the group of four blocks in flight (lane g: block 4 bq + g)
+    f16x8 shf[2], slf[2];
+    auto load_sums = [&](uint32_t bq) {
+        const uint32_t blk = 4 * bq + g;
+        const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const size_t o = (size_t)min(n0 + 32u * wx + 16u * tt + r, P.n - 1) * nsub + (size_t)min(blk, nb - 1) * 8;
+            const f16x8 a = *(const f16x8*)(SH + o), c = *(const f16x8*)(SL + o);
+            shf[tt] = blk < nb ? a : z;
+            slf[tt] = blk < nb ? c : z;
+        }
+    };
+
+    T3W W0, W1;
+    load_w(W0, 0);
+    fetch_x(stage0, 0);
+    fetch_x(stage1, 1);
+    load_sums(0);
+    t3_dequant<0>(W0, 0, nb, As, Dd, Amh, Aml, wave, r, g);
+    store_x(stage0, 0);
+    __syncthreads();
+
+    // one half block: compute half (b, hf) out of buffers hf, produce the next half into buffers hf ^ 1
+    // (stage registers: half h + 1 sits in stage[hf ^ 1]; half h + 2 is requested into stage[hf], free since half h was stored)
+    auto half = [&](uint32_t b, int hf, const T3W& Rc, T3W& Rn) {
+        if (hf == 0) load_w(Rn, b + 1);
+        if (hf == 0) fetch_x(stage0, 2 * b + 2); else fetch_x(stage1, 2 * b + 3);
+        const f16* ab = As + (size_t)hf * 128 * T3_LR + (64u * wy + r) * T3_LR + 8u * g;
+        const f16* xb = Xs + (size_t)hf * 128 * T3_LR + (32u * wx + r) * T3_LR + 8u * g;
+        // the fragments of step ks + 1 are read while step ks multiplies (two register sets; the compiler barriers keep the reads of a step
+        // together and one step ahead -- left alone the scheduler waits for each step's reads right before its MFMAs: 23 waits per half)
+        f16x8 fa[2][4], fb[2][2];
+        auto frags = [&](int set, int ks) {
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) fa[set][rt] = *(const f16x8*)(ab + rt * 16 * T3_LR + ks * 32);
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) fb[set][tt] = *(const f16x8*)(xb + tt * 16 * T3_LR + ks * 32);
+        };
+        frags(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            asm volatile("" ::: "memory");
+            if (ks < 3) frags((ks + 1) & 1, ks + 1);
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) { if (DIAG == 3) acc[rt][tt][0] += (float)fa[ks & 1][rt][0] * (float)fb[ks & 1][tt][0]; else acc[rt][tt] = mfma16(fa[ks & 1][rt], fb[ks & 1][tt], acc[rt][tt]); }
+        }
+        asm volatile("" ::: "memory");
+        if (hf == 0 && ((b & 3u) == 3u || b + 1 == nb)) {
+            // the min term of this group of (up to) four blocks: A_min (LDS, complete since the last barrier) x the input sums
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                const uint32_t ro = (64u * wy + 16u * rt + r) * T3_MR + 8u * g;
+                const f16x8 ah = *(const f16x8*)(Amh + ro), al = *(const f16x8*)(Aml + ro);
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    total[rt][tt] = mfma16(ah, shf[tt], total[rt][tt]);
+                    total[rt][tt] = mfma16(ah, slf[tt], total[rt][tt]);
+                    total[rt][tt] = mfma16(al, shf[tt], total[rt][tt]);
+                }
+            }
+            load_sums((b >> 2) + 1);            // the next group's sums (clamped / zeroed beyond the end)
+        }
+        if (hf == 1) {
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                const f32x4v dv = *(const f32x4v*)(Dd + (b & 1u) * 128u + 64u * wy + 16u * rt + 4u * g);
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) total[rt][tt][i] = __builtin_fmaf(dv[i], acc[rt][tt][i], total[rt][tt][i]);
+                    acc[rt][tt] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
+        // produce the next half
+        if (hf == 0) t3_dequant<1>(Rc, b, nb, As + (size_t)128 * T3_LR, Dd, Amh, Aml, wave, r, g);
+        else if (b + 1 < nb) t3_dequant<0>(Rn, b + 1, nb, As, Dd, Amh, Aml, wave, r, g);
+        if (hf == 0) store_x(stage1, 1u); else store_x(stage0, 0u);
+        __syncthreads();
+    };
+    for (uint32_t b = 0; b < nb; b += 2) {          // uniform over the workgroup
+        half(b, 0, W0, W1);
+        half(b, 1, W0, W1);
+        if (b + 1 >= nb) break;
+        half(b + 1, 0, W1, W0);
+        half(b + 1, 1, W1, W0);
+    }
+
+    // store: lane owns rows m0 + 64 wy + 16 rt + 4g + (0..3) of token n0 + 32 wx + 16 tt + r
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const uint32_t tok = n0 + 32u * wx + 16u * tt + r, row = m0 + 64u * wy + 16u * rt + 4u * g;
+            if (tok >= P.n || row >= P.m) continue;
+            float o[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = act_apply(P.act, total[rt][tt][i] * P.scale);
+            const size_t oo = (size_t)tok * P.os + row;
+            if (P.has_res) {
+                const size_t ro = (size_t)tok * P.rs + row;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = (P.out32 ? o[i] : r16(o[i])) + (P.res32 ? ((const float*)P.res_p)[ro + i] : (float)((const f16*)P.res_p)[ro + i]);
+            }
+            if (P.out32) *(f32x4v*)((float*)P.out_p + oo) = (f32x4v){o[0], o[1], o[2], o[3]};
+            else { typedef _Float16 f16x4 __attribute__((ext_vector_type(4))); *(f16x4*)((f16*)P.out_p + oo) = (f16x4){(f16)o[0], (f16)o[1], (f16)o[2], (f16)o[3]}; }
+        }
+}
+
+int gemm_tile3_launch(hipStream_t s, const GemmBatch& T3, uint32_t row_tiles, uint32_t n, void* xsum, size_t xsum_cap) {
+    if (T3.njobs <= 0 || !xsum) return -1;
+    T3Batch B;
+    B.g = T3;
+    // one pair of sum arrays per DISTINCT input (r, k, v of a layer read three different shifted inputs; a repeated one is summed once)
+    size_t used = 0;
+    const f16* seen_x[GEMM_MAX_JOBS];
+    int nseen = 0;
+    for (int q = 0; q < T3.njobs; ++q) {
+        const GemmParams& P = T3.jobs[q];
+        int hit = -1;
+        for (int u = 0; u < q; ++u)
+            if (T3.jobs[u].x == P.x && T3.jobs[u].xs == P.xs && T3.jobs[u].k == P.k) { hit = u; break; }
+        if (hit >= 0) { B.sh[q] = B.sh[hit]; B.sl[q] = B.sl[hit]; continue; }
+        const size_t cnt = (size_t)n * (P.k >> 5), bytes = (cnt * 2 + 255) & ~(size_t)255;
+        if (used + 2 * bytes > xsum_cap) return -1;
+        f16* sh = (f16*)((char*)xsum + used);
+        f16* sl = (f16*)((char*)xsum + used + bytes);
+        used += 2 * bytes;
+        B.sh[q] = sh; B.sl[q] = sl;
+        seen_x[nseen++] = P.x;
+        xsum_kernel<<<dim3((uint32_t)((cnt + 255) / 256)), 256, 0, s>>>(P.x, P.xs, n, P.k >> 5, sh, sl);
+    }
+    (void)seen_x;
+    const char* de = getenv("WRK_T3_DIAG");
+    const int diag = de ? atoi(de) : 0;
+    const dim3 grid(row_tiles, (n + T3_TOK - 1) / T3_TOK);
+#define T3_GO(D) do { if (!lds_attr_once((const void*)gemm_tile3_kernel<D>, T3_LDS)) return -1; gemm_tile3_kernel<D><<<grid, 512, T3_LDS, s>>>(B); } while (0)
+    if (diag == 1) T3_GO(1); else if (diag == 2) T3_GO(2); else if (diag == 3) T3_GO(3); else T3_GO(0);
+#undef T3_GO
+    return 0;
+}
+
+}  // namespace wrk

@@ -36,7 +36,12 @@ struct wrk_ctx {
     int num_cu = 256;
     void* staging = nullptr;            // pinned host staging for wrk_buf_write
     size_t staging_bytes = 0;
+    // scratch of the prefill GEMM (sub-block input sums of the stacked tokens); grown outside captures, never shrunk, one per context:
+    // the programs of a context run on one submission stream, in order
+    void* gemm_scratch = nullptr;
+    size_t gemm_scratch_cap = 0;
 };
+int32_t wrk_ctx_reserve_gemm_scratch(wrk_ctx* ctx, size_t bytes);      // WRK_OK also when it cannot grow now (inside a capture): the GEMM then keeps its older kernels
 
 struct wrk_buf {
     wrk_ctx* ctx;
@@ -205,6 +210,10 @@ struct MatJob {
     uint32_t* ks_cnt = nullptr;
     size_t ks_part_cap = 0;         // floats
     uint32_t ks_cnt_cap = 0;
+    // third-generation prefill tile (>= 512 stacked tokens, Q4_K): scratch for the sub-block input sums, taken from the first job of a
+    // launch (wrk_ctx::gemm_scratch); nullptr = the kernel is not used
+    void* xsum = nullptr;
+    size_t xsum_cap = 0;            // bytes
 };
 uint32_t matvec_num_wg(const MatJob* jobs, int njobs, int num_cu, uint32_t* rows_per_wg);
 // dry_run: classify only (0 = a launch would honour every job's prologue / carry request, -3 = it cannot)

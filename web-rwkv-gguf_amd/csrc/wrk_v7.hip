@@ -60,6 +60,13 @@ int32_t wrk_v7_model::ensure_scratch(uint32_t T, uint32_t NH) {
     }
     WRK_HIP(ctx, hipMalloc(&scratch, off));
     WRK_HIP(ctx, hipMemsetAsync(scratch, 0, off, ctx->stream));
+    if (nt >= 512 && act_dtype == WRK_F16) {
+        // prefill GEMM (wrk_gemm3.hip): sub-block input sums of the stacked tokens, hi + lo f16 per 32 inputs, for the up to three distinct
+        // inputs of a launch (r, k, v) or the F-wide ffn vector
+        const size_t widest = std::max<size_t>(3 * D, F);
+        const int32_t rs = wrk_ctx_reserve_gemm_scratch(ctx, (size_t)nt * (widest / 32) * 4 + 8 * 1024);
+        if (rs != WRK_OK) return rs;
+    }
     char* b = (char*)scratch;
     ni = 0;
     s.input = b + o_named[ni++]; s.x = b + o_named[ni++]; s.att_x = b + o_named[ni++]; s.att_v0 = b + o_named[ni++];
@@ -101,6 +108,7 @@ static wrk::MatJob mj(const wrk_matrix* m, DTensor in, DTensor out, uint32_t act
 
 static int32_t mm(wrk_ctx* ctx, const wrk_matrix* m, DTensor in, DTensor out, uint32_t act) {
     wrk::MatJob j = mj(m, in, out, act);
+    j.xsum = ctx->gemm_scratch; j.xsum_cap = ctx->gemm_scratch_cap;
     int rc = -2;
     if (in.shape[1] * in.shape[2] >= wrk::gemm_min_tokens()) rc = wrk::matmul_mfma(ctx->op_stream(), j, ctx->num_cu);
     if (rc == -2) rc = wrk::matvec(ctx->op_stream(), &j, 1, ctx->num_cu);
@@ -110,8 +118,10 @@ static int32_t mm(wrk_ctx* ctx, const wrk_matrix* m, DTensor in, DTensor out, ui
 // several matrices x the same token count in one MFMA launch per kernel family; per-matrix launches when the GEMM declines
 static int32_t mm_group(wrk_ctx* ctx, wrk::MatJob* jobs, int n) {
     const uint32_t T = jobs[0].in.shape[1] * jobs[0].in.shape[2];
+    jobs[0].xsum = ctx->gemm_scratch; jobs[0].xsum_cap = ctx->gemm_scratch_cap;
     if (T >= wrk::gemm_min_tokens() && wrk::matmul_mfma_multi(ctx->op_stream(), jobs, n, ctx->num_cu) == 0) return WRK_OK;
     for (int i = 0; i < n; ++i) {
+        jobs[i].xsum = ctx->gemm_scratch; jobs[i].xsum_cap = ctx->gemm_scratch_cap;
         int rc = -2;
         if (T >= wrk::gemm_min_tokens()) rc = wrk::matmul_mfma(ctx->op_stream(), jobs[i], ctx->num_cu);
         if (rc == -2) rc = wrk::matvec(ctx->op_stream(), &jobs[i], 1, ctx->num_cu);

@@ -540,6 +540,7 @@ int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_
     auto run_jobs = [&](MatJob* jobs, int n) -> int {
         if (!single && T >= gemm_min_tokens()) {
             jobs[0].ks_part = s.ks_part; jobs[0].ks_cnt = s.ks_cnt; jobs[0].ks_part_cap = s.ks_part_cap; jobs[0].ks_cnt_cap = s.ks_cnt_cap;
+            jobs[0].xsum = ctx->gemm_scratch; jobs[0].xsum_cap = ctx->gemm_scratch_cap;
             if (matmul_mfma_multi(q, jobs, n, ctx->num_cu) == 0) return 0;      // all matrices of the stage in one launch
             for (int i = 0; i < n; ++i) {
                 int rc = matmul_mfma(q, jobs[i], ctx->num_cu);
