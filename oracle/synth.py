@@ -79,6 +79,9 @@ CONFIGS: Dict[str, V7Config] = {
     "small": V7Config(3, 512, 2048, 1000, 64, 32, 32, 32, 64),
     "0.1B": V7Config(12, 768, 3072, 65536, 64, 64, 64, 32, 128),
     "1.5B": V7Config(24, 2048, 8192, 65536, 64, 96, 96, 64, 256),
+    # three layers of the 1.5B LAYER SHAPE (D = 2048, F = 8192, 32 heads, the real LoRA ranks) with a small vocabulary: the widths of the
+    # headline model at a size the NumPy oracle follows buffer by buffer (tests/test_gpu_layer_parity.py)
+    "1.5B-3L": V7Config(3, 2048, 8192, 1024, 64, 96, 96, 64, 256),
     "2.9B": V7Config(32, 2560, 10240, 65536, 64, 96, 96, 64, 320),
 }
 

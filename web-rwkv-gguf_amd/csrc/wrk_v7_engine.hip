@@ -222,7 +222,8 @@ __device__ __forceinline__ float eng_finish(const EngFin& f, uint32_t row, float
 // (0, 1) of a batch as one granule, lane 1 rows (2, 3).  `gidx(row)` = granule index of the pair that starts at `row`.
 template <int KIND, bool R16, int XI, int RB, class GIDX>
 __device__ __forceinline__ void eng_rows(const lds_u8* slot, uint32_t row_bytes, uint32_t K, const ENG_LDS f16* xs, uint32_t row0, uint32_t r_begin,
-                                         uint32_t r_end, const EngFin& fin, unsigned long long* gran, uint32_t tag, GIDX gidx, f16* plain_out, uint32_t lane) {
+                                         uint32_t r_end, const EngFin& fin, ENG_LDS uint32_t* pub, unsigned long long* gran, uint32_t tag, GIDX gidx,
+                                         uint32_t lane) {
     if (r_begin >= r_end) return;
     const uint32_t kpad = (K + 15u) & ~15u;
     const uint32_t nch = num_chunks<KIND>(K, kpad);
@@ -259,11 +260,20 @@ __device__ __forceinline__ void eng_rows(const lds_u8* slot, uint32_t row_bytes,
             if (ra < r_end) {
                 const float o0 = eng_finish(fin, row0 + ra, lane ? v[2] : v[0]) * fin.post;
                 const float o1 = eng_finish(fin, row0 + ra + 1, lane ? v[3] : v[1]) * fin.post;
-                eng_store_granule(gran + gidx(row0 + ra), tag, pack_h2(o0, o1));
-                if (plain_out) { plain_out[row0 + ra] = (f16)o0; plain_out[row0 + ra + 1] = (f16)o1; }
+                if (pub) pub[ra >> 1] = pack_h2(o0, o1);    // published by ONE wave, coalesced (eng_publish)
+                else eng_store_granule(gran + gidx(row0 + ra), tag, pack_h2(o0, o1));
             }
         }
     }
+}
+
+// The row pairs of a workgroup leave as granules from ONE wave, consecutive lanes on consecutive pairs.  Measured per stage (it costs a
+// barrier): the ffn vector's hand-off (4 096 granules: 3.5 -> 2.6 us) gains from it; K1's and K3's do not (their 1.5 - 2.3 us turned out to
+// be the loader's DMA bursts in front of the polls, not the scattered 8-byte stores) and keep storing from every wave.
+template <class GIDX>
+__device__ __forceinline__ void eng_publish(const ENG_LDS uint32_t* pub, uint32_t nrows, uint32_t row0, unsigned long long* gran, uint32_t tag, GIDX gidx,
+                                            uint32_t lane) {
+    for (uint32_t i = lane; 2 * i < nrows; i += 64) eng_store_granule(gran + gidx(row0 + 2 * i), tag, pub[i]);
 }
 
 // LN + token shift of the layer input (dmv_body PRO 1, one input vector): x (LDS, f16) -> xs = mix(LN(x), prev, mixw), ln_out = LN(x).
@@ -334,6 +344,7 @@ __global__ void __launch_bounds__((NCW + 2) * 64) v7_engine_kernel(const EngArgs
     ENG_LDS uint32_t* abort_flag = (ENG_LDS uint32_t*)(smem + S.lds_misc + 1008);
     ENG_LDS float* red = (ENG_LDS float*)(smem + S.lds_misc);                // 8 floats
     ENG_LDS float* part = (ENG_LDS float*)(smem + S.lds_misc + 64);          // 32 rows x 4 K quarters
+    ENG_LDS uint32_t* pub = (ENG_LDS uint32_t*)(smem + S.lds_misc + 64);     // K1 / K3 / K5: the payload of every row pair of the workgroup (<= 128)
     ENG_LDS f16* xraw0 = (ENG_LDS f16*)(smem + S.lds_xraw0);
     ENG_LDS f16* xraw1 = (ENG_LDS f16*)(smem + S.lds_xraw1);
     ENG_LDS f16* xs = (ENG_LDS f16*)(smem + S.lds_xs);
@@ -392,30 +403,26 @@ __global__ void __launch_bounds__((NCW + 2) * 64) v7_engine_kernel(const EngArgs
         // stage's gather is over (this one) 0.604 - 0.608; every burst between the end of K1 and K3's gather 0.616 (the head workgroups'
         // K3 slot then lands late); a trickle of 6 / 10 pieces behind every barrier 0.79 / 0.73 (the loader arrives late at the LN
         // barriers).  profiles/r03_engine_ab.txt.
-        uint32_t pending = 0;                               // 1, 3, 5, 6: slot whose stage has just ended; 0 none
-        auto refill = [&](uint32_t l) {
-            if (pending == 1) fill1(l + 1);
-            else if (pending == 3) fill3(l + 1);
-            else if (pending == 5) fill5(l + 1);
-            else if (pending == 6) fill6(l);                // issued inside the next layer's K1: `l` is already the next layer
-            pending = 0;
-        };
+        // (kept: K1's slot is refilled the moment K1 ends -- nothing of this workgroup polls until K3's gather, 4 us later; the others go out
+        // behind the first barrier of a stage whose own phase drains them before the NEXT gather polls: W_o's slot behind K5's, the ffn key
+        // slot behind K6's, the ffn value slot behind the next K1's.  57 pieces behind K5's first barrier made the loader late at the LN
+        // barriers (+1 us); the 47 KB K1 burst behind K3's ran into the x1 gather (2.3 us for that hand-off).)
         fill1(S.layer_begin); fill3(S.layer_begin); fill5(S.layer_begin); fill6(S.layer_begin);
+        bool p6 = false;                                    // the previous layer's K6 has ended: its slot waits for this layer's K1
         for (uint32_t l = S.layer_begin; l < S.layer_end; ++l) {
             const bool more = l + 1 < S.layer_end;
             // K1
             eng_wait_vm(issued - m1);
             ENG_BAR();
             if (*abort_flag) break;
-            refill(l);
+            if (p6) { fill6(l); p6 = false; }
             ENG_BAR(); ENG_BAR(); ENG_BAR();
             ENG_STAMP(l, 0);
-            if (more) pending = 1;
+            if (more) fill1(l + 1);                         // K1's own slot at once: until K3's gather this workgroup polls nothing (a head workgroup has no K1 rows)
             // K2
             if (is_head) {
                 ENG_BAR();
                 if (*abort_flag) break;
-                refill(l);
 #pragma unroll
                 for (int i = 1; i < ENG_K2_BARRIERS; ++i) ENG_BAR();
             }
@@ -423,23 +430,20 @@ __global__ void __launch_bounds__((NCW + 2) * 64) v7_engine_kernel(const EngArgs
             eng_wait_vm(issued - m3);
             ENG_BAR();
             if (*abort_flag) break;
-            refill(l);
             ENG_BAR();
-            if (more) pending = 3;
             // K5
             eng_wait_vm(issued - m5);
             ENG_BAR();
             if (*abort_flag) break;
-            refill(l);
-            ENG_BAR(); ENG_BAR(); ENG_BAR();
-            if (more) pending = 5;
+            if (more) fill3(l + 1);
+            ENG_BAR(); ENG_BAR(); ENG_BAR(); ENG_BAR();
             // K6
             eng_wait_vm(issued - m6);
             ENG_BAR();
             if (*abort_flag) break;
-            refill(l);
+            if (more) fill5(l + 1);
             ENG_BAR(); ENG_BAR();
-            if (more) pending = 6;
+            p6 = more;
             ENG_FLUSH(l);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -484,7 +488,7 @@ __global__ void __launch_bounds__((NCW + 2) * 64) v7_engine_kernel(const EngArgs
             ENG_STAMP(l, 3);
             ENG_BAR();
             if (*abort_flag) break;
-            ENG_BAR(); ENG_BAR(); ENG_BAR();
+            ENG_BAR(); ENG_BAR(); ENG_BAR(); ENG_BAR();
             // K6: the compute waves poll their own quarters of the ffn vector
             ENG_BAR();
             if (*abort_flag) break;
@@ -573,14 +577,15 @@ __global__ void __launch_bounds__((NCW + 2) * 64) v7_engine_kernel(const EngArgs
                 wave_rows(k1_rows, rb, re);
                 const EngFin fin{J.act, sc_k1, nullptr, 1.0f};
                 const lds_u8* slot = smem + S.lds_slot1;
+                ENG_LDS uint32_t* nopub = nullptr;
                 if (J.f16) {
                     const uint32_t gb = S.g_k1 + J.gbase;
-                    eng_rows<WRK_MAT_F16, false, 4 * XD, 2>(slot, k1_rb, D, xs, k1_row0, rb, re, fin, A.gran, eng_tag(l, 0),
-                                                            [&](uint32_t r) { return gb + (r >> 1); }, (f16*)nullptr, lane);
+                    eng_rows<WRK_MAT_F16, false, 4 * XD, 2>(slot, k1_rb, D, xs, k1_row0, rb, re, fin, nopub, A.gran, eng_tag(l, 0),
+                                                            [&](uint32_t r) { return gb + (r >> 1); }, lane);
                 } else {
                     const uint32_t gb = S.g_k1 + S.g_aux + J.gbase * 32u;
-                    eng_rows<QK, R16, XD, 4>(slot, k1_rb, D, xs, k1_row0, rb, re, fin, A.gran, eng_tag(l, 0),
-                                             [&](uint32_t r) { return gb + (r >> 6) * 96u + ((r & 63u) >> 1); }, (f16*)nullptr, lane);
+                    eng_rows<QK, R16, XD, 4>(slot, k1_rb, D, xs, k1_row0, rb, re, fin, nopub, A.gran, eng_tag(l, 0),
+                                             [&](uint32_t r) { return gb + (r >> 6) * 96u + ((r & 63u) >> 1); }, lane);
                 }
             }
             ENG_STAMP0(l, 3);
@@ -730,8 +735,9 @@ __global__ void __launch_bounds__((NCW + 2) * 64) v7_engine_kernel(const EngArgs
             wave_rows(k3_rows, rb, re);
             const EngFin fin{WRK_ACT_NONE, sc_o, xraw0, 1.0f};
             const uint32_t gb = S.g_x1;
-            eng_rows<QK, R16, XD, 2>(smem + S.lds_slot3, S.rb_d, D, xs, k3_row0, rb, re, fin, A.gran, eng_tag(l, 2), [&](uint32_t r) { return gb + (r >> 1); },
-                                     (f16*)nullptr, lane);
+            ENG_LDS uint32_t* nopub = nullptr;
+            eng_rows<QK, R16, XD, 2>(smem + S.lds_slot3, S.rb_d, D, xs, k3_row0, rb, re, fin, nopub, A.gran, eng_tag(l, 2),
+                                     [&](uint32_t r) { return gb + (r >> 1); }, lane);
         }
         ENG_STAMP0(l, 7);
         ENG_BAR();                                          // K3 done
@@ -747,8 +753,9 @@ __global__ void __launch_bounds__((NCW + 2) * 64) v7_engine_kernel(const EngArgs
             wave_rows(k5_rows, rb, re);
             const EngFin fin{WRK_ACT_SQUARED_RELU, sc_fk, nullptr, 1.0f};
             const uint32_t gb = S.g_k;
-            eng_rows<QK, R16, XD, 4>(smem + S.lds_slot5, S.rb_d, D, xs, k5_row0, rb, re, fin, A.gran, eng_tag(l, 3), [&](uint32_t r) { return gb + (r >> 1); },
-                                     (f16*)nullptr, lane);
+            eng_rows<QK, R16, XD, 4>(smem + S.lds_slot5, S.rb_d, D, xs, k5_row0, rb, re, fin, pub, A.gran, eng_tag(l, 3), [&](uint32_t r) { return gb + (r >> 1); }, lane);
+            ENG_BAR();
+            if (wave == 0) eng_publish(pub, k5_rows, k5_row0, A.gran, eng_tag(l, 3), [&](uint32_t r) { return gb + (r >> 1); }, lane);
         }
         ENG_STAMP0(l, 9);
         ENG_BAR();                                          // K5 done
