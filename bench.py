@@ -402,7 +402,12 @@ def main():
     dist = None
     device = local_rank
     if args.device_map:
-        device = int(args.device_map.split(",")[local_rank])
+        dm = [int(v) for v in args.device_map.split(",")]
+        device = dm[local_rank]
+        if len(set(dm)) < len(dm):
+            # ranks SHARE a GPU (rehearsal): the persistent decode engine needs every CU of its GPU for itself -- two of them would each
+            # hold part of the chip and wait for the rest until their bounded spins give up -- so the shared ranks keep the launches
+            os.environ["WRK_ENGINE"] = "0"
     use_gloo = args.stub_device or args.dist_backend == "gloo"
     if world > 1 or args.force_dist:
         import torch

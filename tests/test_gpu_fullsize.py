@@ -6,7 +6,7 @@ kernel per reference op vs fused; matvec vs MFMA), chunk-split invariance with s
 Tokens are teacher-forced (a free-running arg-max would turn a 1e-2 logit difference into a different continuation).
 Tolerance: the paths differ in f32 summation order only, but an f32 last-bit difference can flip an f16 store and 24
 layers of a random-weight model amplify it; measured between paths on this model: max 0.06, mean 0.008 on logits of
-unit variance -- the bars are 0.2 / 0.03.  Same-path comparisons are exact."""
+unit variance -- the bars are twice that, 0.12 / 0.016.  Same-path comparisons are exact."""
 import os
 import sys
 
@@ -20,7 +20,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 pytestmark = pytest.mark.gpu
-TOL_MAX, TOL_MEAN = 0.2, 0.03
+TOL_MAX, TOL_MEAN = 0.12, 0.016          # 2 x the measured worst between paths (0.06 / 0.008): VERDICT r02 item 6
 
 
 @pytest.fixture(scope="module")
