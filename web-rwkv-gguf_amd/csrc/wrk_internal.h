@@ -162,7 +162,7 @@ void blit(hipStream_t s, DTensor in, DTensor out);
 void affine(hipStream_t s, DTensor x, float scale, float bias);
 void activate(hipStream_t s, DTensor x, uint32_t act);
 void control_k_v7(hipStream_t s, const void* p, DTensor a, DTensor k);
-void time_mix_v7(hipStream_t s, const uint32_t* cursors, DTensor state, DTensor r, DTensor w, DTensor n, DTensor x);
+void time_mix_v7(hipStream_t s, const uint32_t* cursors, DTensor state, DTensor r, DTensor w, DTensor n, DTensor x, uint32_t nseq_hint = 0);   // 0: unknown
 void time_first_v7(hipStream_t s, const void* u, DTensor r, DTensor n, DTensor x);
 void channel_mix_v7(hipStream_t s, const uint32_t* cursors, DTensor state, DTensor v, DTensor x);
 void softmax(hipStream_t s, DTensor x);

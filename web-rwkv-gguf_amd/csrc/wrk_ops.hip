@@ -385,6 +385,36 @@ __global__ void __launch_bounds__(256) time_mix_v7_kernel(const uint32_t* __rest
 }
 
 
+// The s-th sequence of a dispatch (the s-th token t whose cursor says "first token of its sequence": cursor.token == t), found by every wave
+// for itself: 16 cursors per lane in flight, a ballot per 64 tokens.  Round 3: the chunk kernels are launched over (head, sequence slot)
+// instead of (head, token) -- a 32 x 128-token chunk was 131 072 workgroups of which 1 024 stayed, placed wherever the dispatcher happened
+// to have a free slot (some SIMDs three live waves, some none).
+__device__ __forceinline__ bool find_sequence(const uint32_t* __restrict__ cursors, uint32_t T, uint32_t s, Cursor& out) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t seen = 0;
+    for (uint32_t base = 0; base < T; base += 1024) {
+        uint32_t c[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) c[u] = cursors[min(base + 64 * u + lane, T - 1)];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const uint32_t idx = base + 64 * u + lane;
+            const bool first = idx < T && ((c[u] >> 8) & 0xffffu) == idx;
+            const unsigned long long mask = __ballot(first);
+            const uint32_t cnt = (uint32_t)__popcll(mask);
+            if (s < seen + cnt) {
+                const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+                const unsigned long long hit = __ballot(first && rank == s - seen);
+                const int src = __ffsll((long long)hit) - 1;
+                out = unpack_cursor((uint32_t)__builtin_amdgcn_readlane((int)c[u], src));
+                return true;
+            }
+            seen += cnt;
+        }
+    }
+    return false;
+}
+
 // Fast path for the layout the runtime uses (dense f16 r, w, n, x; f32 state): same arithmetic, different mapping.
 // Thread (i = tid >> 2, part = tid & 3) owns S[16 part .. 16 part + 15][i], so the two reductions over j are 16
 // in-register FMAs plus two quad shuffles -- no LDS traffic and no workgroup barrier for them.  Only w~ (two
@@ -392,12 +422,12 @@ __global__ void __launch_bounds__(256) time_mix_v7_kernel(const uint32_t* __rest
 // double-buffered LDS row, one barrier per token.  The f16 inputs of the next token are prefetched while the current
 // one is multiplied.  Measured (1.5B, 128-token chunk): 292 us -> see DESIGN.md.
 __global__ void __launch_bounds__(256) time_mix_v7_fast_kernel(const uint32_t* __restrict__ cursors, DTensor st, DTensor r, DTensor w,
-                                                                DTensor n, DTensor x) {
+                                                                DTensor n, DTensor x, uint32_t ntok) {
     constexpr int S = 64;
     __shared__ __attribute__((aligned(16))) float sh_w[2][S];
-    const uint32_t head = blockIdx.x, t0 = blockIdx.y;
-    const Cursor cur = unpack_cursor(cursors[t0]);
-    if (cur.token != t0) return;                     // not the first token of a sequence chunk
+    const uint32_t head = blockIdx.x;
+    Cursor cur;
+    if (!find_sequence(cursors, ntok, blockIdx.y, cur)) return;       // fewer sequences in this dispatch than slots (uniform over the workgroup)
     const uint32_t tid = threadIdx.x, i = tid >> 2, part = tid & 3u;
     const uint32_t ch = head * S + i;
     const uint32_t tend = cur.token + cur.len;
@@ -492,17 +522,203 @@ __global__ void __launch_bounds__(256) time_mix_v7_fast_kernel(const uint32_t* _
     for (int jj = 0; jj < 16; ++jj) sbase[dt_index(st, ch, 1 + part * 16 + jj, cur.batch)] = Sreg[jj];
 }
 
+// v_fma_mix_f32 with an f16 operand taken from half HI of a dword, unconverted (plain asm: the compiler may move and drop them)
+template <int HI> __device__ __forceinline__ float mix_fma(uint32_t h2, float f, float acc) {           // (float)h * f + acc, one rounding
+    if (HI) asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(h2), "v"(f));
+    else asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(h2), "v"(f));
+    return acc;
+}
+template <int HI> __device__ __forceinline__ float mix_fma_neg(float f, uint32_t h2, float acc) {       // f * -(float)h + acc
+    if (HI) asm("v_fma_mix_f32 %0, %1, -%2, %0 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "+v"(acc) : "v"(f), "v"(h2));
+    else asm("v_fma_mix_f32 %0, %1, -%2, %0 op_sel_hi:[0,1,0]" : "+v"(acc) : "v"(f), "v"(h2));
+    return acc;
+}
+template <int HI> __device__ __forceinline__ float mix_fma0(uint32_t h2, float f) {                     // (float)h * f + 0: head of a chain
+    float d;
+    if (HI) asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(f));
+    else asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(f));
+    return d;
+}
+template <int HI> __device__ __forceinline__ float mix_fma_neg0(float f, uint32_t h2) {                 // f * -(float)h + 0
+    float d;
+    if (HI) asm("v_fma_mix_f32 %0, %1, -%2, 0 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(d) : "v"(f), "v"(h2));
+    else asm("v_fma_mix_f32 %0, %1, -%2, 0 op_sel_hi:[0,1,0]" : "=v"(d) : "v"(f), "v"(h2));
+    return d;
+}
+template <int HI> __device__ __forceinline__ float mix_mul(uint32_t h2, float f, float negzero) {       // (float)h * f rounded to f32 (x + -0 = x)
+    float d;
+    if (HI) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(f), "v"(negzero));
+    else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(f), "v"(negzero));
+    return d;
+}
+
+// Round 3: ONE WAVE per (head, sequence).  Lane i owns the whole state column S[0..63][i] in 64 registers, so both reductions over j are
+// private FMA chains (no shuffles, no barrier, no workgroup) and every per-j quantity -- w~, b~ = kk * a, r, k, a~ = -kk -- is the SAME for all
+// lanes: lane j prepares channel j of the NEXT token once (two transcendentals, one product; the quad kernel above converted each of them in 64
+// threads: 49 conversions + 29 register moves of its ~250 instructions per wave and step, times four waves per head) and leaves it in a
+// double-buffered LDS row that the wave reads back at a uniform address (broadcast).  ~330 vector instructions per head and step instead of
+// ~1000; 32 sequences x 32 heads = one wave per SIMD of the chip instead of two rounds of two 4-wave workgroups per CU.
+// The summation orders are those of the quad kernel (16 chains of 4, the same trees), so the two are bit-identical.
+__global__ void __launch_bounds__(64) time_mix_v7_wave_kernel(const uint32_t* __restrict__ cursors, DTensor st, DTensor r, DTensor w, DTensor n,
+                                                               DTensor x, uint32_t ntok) {
+    constexpr int S = 64;
+    struct Slot { float wt[S], bt[S]; f16 r[S], k[S], q[S]; };
+    __shared__ __attribute__((aligned(16))) Slot sh[2];
+    const uint32_t head = blockIdx.x;
+    Cursor cur;
+    if (!find_sequence(cursors, ntok, blockIdx.y, cur)) return;       // fewer sequences in this dispatch than slots
+    const uint32_t lane = threadIdx.x;
+    const uint32_t ch = head * S + lane;
+    const uint32_t tend = cur.token + cur.len;
+
+    // token-shift carry: state row 0 <- att_x of the sequence's last token (read before it is overwritten)
+    dt_store(st, dt_index(st, ch, 0, cur.batch), dt_load(x, dt_index(x, lane, head, tend - 1)));
+    float Sreg[S];
+    float* sbase = (float*)st.p;
+#pragma unroll
+    for (int j = 0; j < S; ++j) Sreg[j] = sbase[dt_index(st, ch, 1 + j, cur.batch)];
+
+    struct Tok { f16 w, a, q, v, r, k; };
+    const size_t rstep = (size_t)r.stride[1] * r.stride[0], nstep = (size_t)n.stride[1] * n.stride[0];
+    const size_t wstep = (size_t)w.stride[1] * w.stride[0], xstep = (size_t)x.stride[1] * x.stride[0];
+    const f16* rp = (const f16*)r.p + dt_index(r, lane, head, cur.token);
+    const f16* kp = (const f16*)n.p + dt_index4(n, lane, head, cur.token, 0);
+    const f16* vp = (const f16*)n.p + dt_index4(n, lane, head, cur.token, 1);
+    const f16* ap = (const f16*)n.p + dt_index4(n, lane, head, cur.token, 2);
+    const f16* qp = (const f16*)n.p + dt_index4(n, lane, head, cur.token, 3);
+    const f16* wp = (const f16*)w.p + dt_index(w, lane, head, cur.token);
+    f16* xp = (f16*)x.p + dt_index(x, lane, head, cur.token);
+    uint32_t lpos = cur.token;
+    float negzero = -0.0f;
+    asm volatile("" : "+v"(negzero));
+    auto load_tok = [&](Tok& T, bool adv) {       // unconditional loads: the pointers stop at the last token
+        const size_t rs = adv ? rstep : 0, ns = adv ? nstep : 0, ws = adv ? wstep : 0;
+        rp += rs; kp += ns; vp += ns; ap += ns; qp += ns; wp += ws;
+        lpos += adv ? 1u : 0u;
+        T.w = *wp; T.a = *ap; T.q = *qp; T.v = *vp; T.r = *rp; T.k = *kp;
+    };
+    auto prepare = [&](const Tok& T, Slot& L) {   // lane j: channel j of a token
+        L.wt[lane] = __expf(-0.606531f * act_sigmoid((float)T.w));
+        L.bt[lane] = (float)T.q * (float)T.a;     // b~ = kk * a (exact in f32)
+        L.r[lane] = T.r; L.k[lane] = T.k; L.q[lane] = T.q;
+    };
+    // Tokens are requested NPF - 1 steps ahead (a memory round trip under load is about three steps): a ring of register sets with STATIC
+    // indices -- rotating the sets (T0 = T1 ...) moves registers whose loads are still in flight, which is a wait for all of them.  The main
+    // loop takes whole groups of NPF tokens without any control flow; the last len % NPF tokens run behind uniform branches.
+    constexpr int NPF = 4;
+    Tok T[NPF];
+    load_tok(T[0], false);
+#pragma unroll
+    for (int u = 1; u < NPF; ++u) load_tok(T[u], lpos + 1 < tend);
+    prepare(T[0], sh[cur.token & 1u]);
+    auto step = [&](uint32_t t, Tok& Tc, const Tok& Tn) {
+        const Slot& L = sh[t & 1u];
+        prepare(Tn, sh[(t + 1) & 1u]);              // the next token's row: off the critical path of this step
+        const float vv = (float)Tc.v;
+        load_tok(Tc, lpos + 1 < tend);              // this register set is free: token t + NPF (the last one again once the chunk ends)
+        // sa[i] = sum_j S[j][i] * a~[j]: 16 chains (part p = j / 16, c = j % 4) of 4, as in the quad kernel.  The f16 operands go into
+        // v_fma_mix_f32 as they are (the compiler converts each of them first and then packs pairs with register moves: 196 + 136 instructions)
+        // LDS reads are requested a group ahead of their use (left alone the compiler reads each operand right in front of its first use and
+        // waits: 56 exposed LDS round trips per step)
+        u32x4 q8[8];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) q8[g] = *(const u32x4*)(L.q + 8 * g);
+        struct Grp { u32x4 k, r; f32x4 w0, w1, b0, b1; };
+        auto load_grp = [&](Grp& G, int g) {
+            G.k = *(const u32x4*)(L.k + 8 * g); G.r = *(const u32x4*)(L.r + 8 * g);
+            G.w0 = *(const f32x4*)(L.wt + 8 * g); G.w1 = *(const f32x4*)(L.wt + 8 * g + 4);
+            G.b0 = *(const f32x4*)(L.bt + 8 * g); G.b1 = *(const f32x4*)(L.bt + 8 * g + 4);
+        };
+        Grp G0, G1;
+        load_grp(G0, 0);
+        float ch16[16];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                const int j = 8 * g + e, c = (j >> 4) * 4 + (j & 3);
+                if ((j & 15) < 4) {         // head of its chain
+                    ch16[c] = mix_fma_neg0<0>(Sreg[j], q8[g][e >> 1]);
+                    ch16[c + 1] = mix_fma_neg0<1>(Sreg[j + 1], q8[g][e >> 1]);
+                } else {
+                    ch16[c] = mix_fma_neg<0>(Sreg[j], q8[g][e >> 1], ch16[c]);
+                    ch16[c + 1] = mix_fma_neg<1>(Sreg[j + 1], q8[g][e >> 1], ch16[c + 1]);
+                }
+            }
+        }
+        float P[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) P[p] = (ch16[4 * p] + ch16[4 * p + 1]) + (ch16[4 * p + 2] + ch16[4 * p + 3]);
+        const float sa = (P[0] + P[1]) + (P[2] + P[3]);
+        const f32x2 sa2 = {sa, sa};
+        auto update = [&](const Grp& G, int g) {
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                const int j = 8 * g + e, c = (j >> 4) * 4 + (j & 3);
+                const f32x2 wj = e < 4 ? (f32x2){G.w0[e & 3], G.w0[(e & 3) + 1]} : (f32x2){G.w1[e & 3], G.w1[(e & 3) + 1]};
+                const f32x2 bj = e < 4 ? (f32x2){G.b0[e & 3], G.b0[(e & 3) + 1]} : (f32x2){G.b1[e & 3], G.b1[(e & 3) + 1]};
+                const f32x2 s2 = {Sreg[j], Sreg[j + 1]};
+                const f32x2 kv = {mix_mul<0>(G.k[e >> 1], vv, negzero), mix_mul<1>(G.k[e >> 1], vv, negzero)};      // k * v, rounded once
+                const f32x2 sn = (s2 * wj + kv) + sa2 * bj;
+                Sreg[j] = sn[0];
+                Sreg[j + 1] = sn[1];
+                if ((j & 15) < 4) {
+                    ch16[c] = mix_fma0<0>(G.r[e >> 1], sn[0]);
+                    ch16[c + 1] = mix_fma0<1>(G.r[e >> 1], sn[1]);
+                } else {
+                    ch16[c] = mix_fma<0>(G.r[e >> 1], sn[0], ch16[c]);
+                    ch16[c + 1] = mix_fma<1>(G.r[e >> 1], sn[1], ch16[c + 1]);
+                }
+            }
+        };
+#pragma unroll
+        for (int g = 0; g < 8; g += 2) {
+            load_grp(G1, g + 1);
+            update(G0, g);
+            if (g + 2 < 8) load_grp(G0, g + 2);
+            update(G1, g + 1);
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) P[p] = (ch16[4 * p] + ch16[4 * p + 1]) + (ch16[4 * p + 2] + ch16[4 * p + 3]);
+        const float y = (P[0] + P[1]) + (P[2] + P[3]);
+        *xp = (f16)y;
+        xp += xstep;
+    };
+    uint32_t tb = cur.token;
+    for (; tb + NPF <= tend; tb += NPF) {
+#pragma unroll
+        for (int u = 0; u < NPF; ++u) step(tb + u, T[u], T[(u + 1) % NPF]);
+    }
+#pragma unroll
+    for (int u = 0; u < NPF - 1; ++u)
+        if (tb + u < tend) step(tb + u, T[u], T[(u + 1) % NPF]);
+#pragma unroll
+    for (int j = 0; j < S; ++j) sbase[dt_index(st, ch, 1 + j, cur.batch)] = Sreg[j];
+}
+
 static bool dense_f16_heads(const DTensor& d) {
     return d.dtype == WRK_F16 && d.shape[0] == 64 && d.stride[0] == 64 && d.offset[0] == 0 && (((uintptr_t)d.p) & 15u) == 0;
 }
 
-void time_mix_v7(hipStream_t s, const uint32_t* cursors, DTensor st, DTensor r, DTensor w, DTensor n, DTensor x) {
+void time_mix_v7(hipStream_t s, const uint32_t* cursors, DTensor st, DTensor r, DTensor w, DTensor n, DTensor x, uint32_t nseq_hint) {
     if (r.shape[2] == 0) return;
-    dim3 grid(r.shape[1], r.shape[2]);
-    if (dense_f16_heads(r) && dense_f16_heads(w) && dense_f16_heads(n) && dense_f16_heads(x) && st.dtype == WRK_F32)
-        time_mix_v7_fast_kernel<<<grid, 256, 0, s>>>(cursors, st, r, w, n, x);
-    else
+    const uint32_t H = r.shape[1], T = r.shape[2];
+    if (dense_f16_heads(r) && dense_f16_heads(w) && dense_f16_heads(n) && dense_f16_heads(x) && st.dtype == WRK_F32) {
+        // sequence slots: at most one sequence per batch of the state and per token.  One wave per head once the sequences of the dispatch
+        // (nseq_hint; unknown = as many as the state has batches) put a wave on three of four SIMDs of the chip, four waves per head below that:
+        // a lone wave issues one vector instruction per ~4 cycles whatever it does (one sequence: 1.19 us per step against 0.84)
+        const uint32_t slots = std::min(T, st.shape[2]);
+        const uint32_t nseq = nseq_hint ? std::min(nseq_hint, slots) : slots;
+        const char* fe = getenv("WRK_WKV_WAVE");                // 0 / 1: A/B and tests (read per call; captured programs keep their kernel)
+        const int force = fe ? atoi(fe) : -1;
+        const bool wave = force >= 0 ? force != 0 : nseq * H >= 768;     // measured (1.5B, 32 heads): 16 sequences 110 k vs 107 k tok/s for four waves, 32 sequences 117 k vs 124 k
+        dim3 grid(H, slots);
+        if (wave) time_mix_v7_wave_kernel<<<grid, 64, 0, s>>>(cursors, st, r, w, n, x, T);
+        else time_mix_v7_fast_kernel<<<grid, 256, 0, s>>>(cursors, st, r, w, n, x, T);
+    } else {
+        dim3 grid(H, T);
         time_mix_v7_kernel<<<grid, 256, 0, s>>>(cursors, st, r, w, n, x);
+    }
 }
 
 // ------------------------------------------------------------------ merged element-wise stages of an RWKV-7 layer (mode 1, multi-token)

@@ -59,6 +59,7 @@ struct wrk_v7_model {
     // stage (LN(ln0) + blit) is part of it; the defaults are the whole model
     uint32_t layer_begin = 0, layer_end = 0xffffffffu;
     bool skip_embed = false;
+    uint32_t wkv_nseq = 0;          // sequences of the job being enqueued (0: unknown): picks the WKV chunk kernel, wrk::time_mix_v7
     // activation dtype of the frame: WRK_F16 = Bundle::<f16> (the reference's default), WRK_F32 = Bundle::<f32> (v7.rs:281-320
     // is generic over F).  F32 frames always take the op-by-op path with the f32-input matvec.
     uint32_t act_dtype = WRK_F16;

@@ -241,7 +241,7 @@ int32_t wrk_v7_model::enqueue_ops(wrk_v7_state* st, uint32_t T, uint32_t NH, boo
             wrk::blit(q, a, nslice(2));
             wrk::blit(q, kk, nslice(3));
         }
-        wrk::time_mix_v7(q, s.cursors, st_att, heads(s.r), heads(s.w), n4, heads(s.att_x));   // 12
+        wrk::time_mix_v7(q, s.cursors, st_att, heads(s.r), heads(s.w), n4, heads(s.att_x), wkv_nseq);   // 12
         if (m_post) wrk::post_wkv_v7(q, s.att_x, s.r, s.g, s.n, L.gn_w->ptr, L.gn_b->ptr, L.r_k->ptr, D, T, GN_EPS);    // 13-15 in one launch
         else {
             wrk::group_norm(q, L.gn_w->ptr, L.gn_b->ptr, heads(s.att_x), GN_EPS);        // 13
@@ -521,6 +521,7 @@ int32_t wrk_v7_infer(wrk_ctx* ctx, wrk_v7_model* m, wrk_v7_state* st, const uint
     // The launches of a job depend only on its shape (token count, header rows, flags): cursors, tokens and header rows
     // are device data.  Capture once per shape and replay (the reference caches the RnnJob of a repeated RnnInfo);
     // a 128-token chunk of one sequence is ~1 400 small launches, which replay at graph rate.
+    m->wkv_nseq = nseq;       // chunk kernel of the WKV state: one wave or four per head (part of the graph key below)
     auto enqueue_job = [&]() -> int32_t {
         int32_t r;
         if (fused) r = m->enqueue_fused_decode(st, T, NH, identity, tokens != nullptr, NH && argmax, false, cursors[0] & 0xff, contiguous);
@@ -536,7 +537,8 @@ int32_t wrk_v7_infer(wrk_ctx* ctx, wrk_v7_model* m, wrk_v7_state* st, const uint
         // bit 5: a non-fused job enqueues the merged launch list in mode 1 and the reference op list in mode 0 -- two graphs
         const uint32_t flags = 16u | (m->act_dtype == WRK_F32 ? 64u : 0u) | (fused ? 1u : 0u) | (identity ? 2u : 0u) | (tokens ? 4u : 0u) | ((NH && argmax) ? 8u : 0u) |
                                ((!fused && mode == 1) ? 32u : 0u) | (fused ? (cursors[0] & 0xffu) << 8 : 0u) | ((fused && contiguous) ? 1u << 16 : 0u) |
-                               ((fused && T == 1 && m->engine_on()) ? 1u << 17 : 0u) | (split_head_env_on() ? 0u : 1u << 18);
+                               ((fused && T == 1 && m->engine_on()) ? 1u << 17 : 0u) | (split_head_env_on() ? 0u : 1u << 18) |
+                               ((!fused && (size_t)nseq * m->d.num_head >= 768) ? 1u << 19 : 0u);
         const wrk_v7_model::GraphKey key{st->uid, T, flags, NH};
         wrk_program* prog = nullptr;
         auto it = m->graphs.find(key);
@@ -637,6 +639,7 @@ int32_t wrk_v7_infer_layer(wrk_ctx* ctx, wrk_v7_model* m, wrk_v7_state* st, uint
     if (rc == WRK_OK && v_first) rc = wrk_buf_write_raw(ctx, m->s.att_v0, v_first, (size_t)T * m->d.num_emb * esz);
     if (rc != WRK_OK) return rc;
     m->layer_begin = layer; m->layer_end = layer + 1; m->skip_embed = true;
+    m->wkv_nseq = nseq;
     // this entry point exists to read the frame buffers of a layer back (wrk_v7_frame_read): the engine keeps them in LDS and granules,
     // so the launches run here; WRK_ENGINE_INSPECT=1 (tests/test_gpu_engine.py) runs the engine's layer instead
     { const char* ei = getenv("WRK_ENGINE_INSPECT"); m->engine_skip_once = !(ei && ei[0] == '1'); }
