@@ -82,6 +82,7 @@ CONFIGS: Dict[str, V7Config] = {
     # three layers of the 1.5B LAYER SHAPE (D = 2048, F = 8192, 32 heads, the real LoRA ranks) with a small vocabulary: the widths of the
     # headline model at a size the NumPy oracle follows buffer by buffer (tests/test_gpu_layer_parity.py)
     "1.5B-3L": V7Config(3, 2048, 8192, 1024, 64, 96, 96, 64, 256),
+    "2.9B-2L": V7Config(2, 2560, 10240, 1024, 64, 96, 96, 64, 320),      # the 2.9B layer shape (rows of 2560 elements: two chunk iterations per wave)
     "2.9B": V7Config(32, 2560, 10240, 65536, 64, 96, 96, 64, 320),
 }
 

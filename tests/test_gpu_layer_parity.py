@@ -154,6 +154,7 @@ def test_several_sequences_decode_layer_by_layer(ctx, mode, nseq):
 
 
 @pytest.mark.parametrize("name,nseq,kw", [("small", 9, {}), ("small", 20, {}), ("tiny", 40, {}), ("small", 12, {"mat": "Q5_K"}),
+                                          ("small", 12, {"mat": "Q8_0"}), ("small", 20, {"mat": "Q8_0"}),      # round 3: Q8_0 body
                                           ("small", 18, {"mat_override": {"time_mix_value": "Q6_K", "channel_mix_value": "Q6_K"}})])
 def test_decode_batches_on_the_k_sliced_gemm(ctx, name, nseq, kw, monkeypatch):
     """5 .. 32 sequences with WRK_GEMM_KS=2: every matrix of the layer goes through the K-sliced MFMA kernel (1 and 2 token tiles; K
@@ -161,6 +162,15 @@ def test_decode_batches_on_the_k_sliced_gemm(ctx, name, nseq, kw, monkeypatch):
     K-split kernels."""
     monkeypatch.setenv("WRK_GEMM_KS", "2")
     run_case(ctx, name, wrk.WEIGHTS_INLINE, kw, 1, [1] * nseq, 2)
+
+
+@pytest.mark.parametrize("nseq", [1, 2])
+def test_real_tensor_mix_at_the_2p9b_layer_shape(ctx, nseq):
+    """Round 3: llama.cpp's Q4_K_M mix (Q6_K attention value and ffn value next to Q4_K, F16 LoRA rows) on rows of 2560
+    elements, 1 / 2 sequences: the three-kind launch of the fused layer (r, k, v + LoRA behind the LN prologue) on the dmv kernels with
+    two chunk iterations per wave -- before, K > 2048 sent this launch (and with it the layer) to the 7-launch MFMA path.  (The buffer table
+    of this case is the split-head one: it passes only if the 5-launch layer ran.  Four sequences stay on the MFMA layer: measured faster.)"""
+    run_case(ctx, "2.9B-2L", wrk.WEIGHTS_INLINE, {"mat_override": {"time_mix_value": "Q6_K", "channel_mix_value": "Q6_K"}}, 1, [1] * nseq, 2)
 
 
 @pytest.mark.parametrize("mode", [0, 1])

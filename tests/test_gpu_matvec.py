@@ -143,6 +143,7 @@ def test_gemm_activation_residual_f16_out_and_vec_agreement(ctx):
     # blocks: a last group of two; 8192: the ffn value shape
     ("Q4_K", 2560, 260, 530), ("Q4_K", 8192, 132, 515), ("Q4_K", 1280, 128, 512),
     ("Q8_0", 2048, 520, 600), ("Q8_0", 1024, 1028, 530), ("Q8_0", 4096, 1100, 520), ("Q8_0", 128, 2052, 640),         # Q8_0: that kernel only
+    ("Q8_0", 2048, 520, 200), ("Q8_0", 1024, 1028, 130), ("Q8_0", 128, 2052, 100), ("Q8_0", 2560, 260, 70),           # round 3: Q8_0 chunks of 48 .. 511 tokens on the same kernel
     ("F16", 2048, 96, 600), ("F16", 2560, 320, 530), ("F16", 256, 2052, 640), ("F16", 1024, 520, 1030)])      # F16 with K % 128 == 0
 def test_gemm_prefill_tile_kernel(ctx, kind, k, m, T):
     """The LDS-tiled prefill kernel (>= 48 stacked tokens of one dense [K, T, 1] stack, >= 64 rows, Q4_K / Q5_K / Q6_K / F16):

@@ -139,12 +139,15 @@ int launch_dmv(hipStream_t s, const MatvecParams& P, uint32_t total_wg, int quan
         if (!dry) hipLaunchKernelGGL(ft, dim3(total_wg, 1), dim3(256), 0, s, bounds[0], bounds[1], bounds[2], bounds[3], bounds[4], bounds[5], bounds[6], bmask, DT);
         return 0;
     }
-    else if (quant2 >= 0) {      // (Q4_K | Q5_K) + Q6_K (+ F16): short rows, LN prologue or none
+    else if (quant2 >= 0) {      // (Q4_K | Q5_K) + Q6_K (+ F16): LN prologue or none; rows up to 4096 elements (round 3: the 2.9B model's K = 2560)
         const int k4 = quant == WRK_MAT_Q6_K ? quant2 : quant;
-        if ((quant != WRK_MAT_Q6_K && quant2 != WRK_MAT_Q6_K) || (k4 != WRK_MAT_Q4_K && k4 != WRK_MAT_Q5_K) || xi != 1 || pro > 1) return -1;
-#define DMV3(A) (pro == 1 ? (r16 ? (dmv_fn)dmv3_kernel<A, true, 1, 1, 1> : (dmv_fn)dmv3_kernel<A, false, 1, 1, 1>) : (r16 ? (dmv_fn)dmv3_kernel<A, true, 1, 0, 1> : (dmv_fn)dmv3_kernel<A, false, 1, 0, 1>))
+        const int lnpro = xi == 1 ? 1 : 2;
+        if ((quant != WRK_MAT_Q6_K && quant2 != WRK_MAT_Q6_K) || (k4 != WRK_MAT_Q4_K && k4 != WRK_MAT_Q5_K) || xi > 2 || (pro != 0 && pro != lnpro)) return -1;
+#define DMV3X(A, X, PR) (r16 ? (dmv_fn)dmv3_kernel<A, true, X, PR, 1> : (dmv_fn)dmv3_kernel<A, false, X, PR, 1>)
+#define DMV3(A) (xi == 1 ? (pro ? DMV3X(A, 1, 1) : DMV3X(A, 1, 0)) : (pro ? DMV3X(A, 2, 2) : DMV3X(A, 2, 0)))
         fn = k4 == WRK_MAT_Q4_K ? DMV3(WRK_MAT_Q4_K) : DMV3(WRK_MAT_Q5_K);
 #undef DMV3
+#undef DMV3X
     }
     else if (xi == 1) fn = pick_dmv_kind<1, 1>(ka, mixf, r16, pro);
     else if (xi == 2) fn = pick_dmv_kind<2, 1>(ka, mixf, r16, pro);

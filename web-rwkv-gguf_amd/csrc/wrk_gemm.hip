@@ -1272,7 +1272,9 @@ __device__ __forceinline__ void gemm_ks_body(const GemmParams& P, const KsJob& E
         stage[i] = *(const f16x8*)(P.x + (size_t)min(tok, P.n - 1) * P.xs + (size_t)b0 * 256 + ch * 8);
     }
     struct WBlk { u32x2 q[4]; u32x2 qh; u32x4 sm; uint32_t dd[4]; };
-    WBlk W[(KIND == WRK_MAT_F16 || KIND == WRK_MAT_Q6_K) ? 1 : BPS];
+    WBlk W[(KIND == WRK_MAT_F16 || KIND == WRK_MAT_Q6_K || KIND == WRK_MAT_Q8_0) ? 1 : BPS];
+    struct W8 { u32x2 q[8]; u32x4 d[4]; };             // Q8_0 (round 3): this lane's 8 codes of each 32-block; the eight block scales of its four C rows
+    W8 V8[KIND == WRK_MAT_Q8_0 ? BPS : 1];
     f16x8 WF[KIND == WRK_MAT_F16 ? BPS : 1][8];
     struct W6 { u32x2 ql[4]; u32x2 qh[2]; u32x4 sc; uint32_t d[4]; };
     W6 V6[KIND == WRK_MAT_Q6_K ? BPS : 1];
@@ -1297,6 +1299,19 @@ __device__ __forceinline__ void gemm_ks_body(const GemmParams& P, const KsJob& E
         for (int u = 0; u < BPS; ++u)
 #pragma unroll
             for (int sb = 0; sb < 8; ++sb) WF[u][sb] = *(const f16x8*)(wr + (size_t)(b0 + u) * 256 + sb * 32 + 8 * g);
+    } else if (KIND == WRK_MAT_Q8_0) {
+        // device row: K int8 codes, then one f16 scale per 32-block (K % 256 == 0 here: the scales of a 256-slice are 16 aligned bytes)
+        const uint8_t* drow[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) drow[i] = P.w + (size_t)min(m0 + 4 * g + i, P.m - 1) * P.row_bytes + K;
+#pragma unroll
+        for (int u = 0; u < BPS; ++u) {
+            const uint32_t b = b0 + u;
+#pragma unroll
+            for (int sb = 0; sb < 8; ++sb) V8[u].q[sb] = *(const u32x2*)(wrow + (size_t)b * 256 + sb * 32 + 8 * g);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) V8[u].d[i] = *(const u32x4*)(drow[i] + (size_t)b * 16);
+        }
     } else {
         const uint32_t hoff = KIND == WRK_MAT_Q4_K ? nb * 128 : nb * 160, soff = hoff + nb * 4;
         const uint8_t* crow[4];
@@ -1339,6 +1354,22 @@ __device__ __forceinline__ void gemm_ks_body(const GemmParams& P, const KsJob& E
             for (int sb = 0; sb < 8; ++sb)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) total[t] = mfma16(WF[u][sb], *(const f16x8*)(xt + 16 * t * ROWF + 256 * u + 32 * sb), total[t]);
+        } else if (KIND == WRK_MAT_Q8_0) {      // as gemm_body: A = the int8 code, one MFMA per 32-block, its scale applied to the f32 sum
+            const W8& R = V8[KIND == WRK_MAT_Q8_0 ? u : 0];
+#pragma unroll
+            for (int sb = 0; sb < 8; ++sb) {
+                const u32x2 q = R.q[sb];
+                const f16x8 a = add8(mul8(codes8(q.x ^ 0x80808080u, q.y ^ 0x80808080u), 32768.0f), -0.25f);       // (code + 128) * 2^-9 - 128 * 2^-9
+                float dsc[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dsc[i] = (float)__builtin_bit_cast(f16, (uint16_t)(R.d[i][sb >> 1] >> (16 * (sb & 1)))) * 512.0f;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const f32x4v acc = mfma16(a, *(const f16x8*)(xt + 16 * t * ROWF + 256 * u + 32 * sb), (f32x4v){0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) total[t][i] = __builtin_fmaf(dsc[i], acc[i], total[t][i]);
+                }
+            }
         } else if (KIND == WRK_MAT_Q6_K) {      // as gemm_body: A = (q6 - 32) * sc with sc = 2 s1 + s0 over two MFMAs, d per 256-block in f32
             const W6& R = V6[KIND == WRK_MAT_Q6_K ? u : 0];
             const uint32_t gsh = 8 * (g >> 1);
@@ -1375,7 +1406,7 @@ __device__ __forceinline__ void gemm_ks_body(const GemmParams& P, const KsJob& E
                 for (int t = 0; t < NT; ++t) total[t][i] = __builtin_fmaf(dd, acc[t][i], total[t][i]);
             }
         } else {
-            const WBlk& R = W[(KIND == WRK_MAT_F16 || KIND == WRK_MAT_Q6_K) ? 0 : u];
+            const WBlk& R = W[(KIND == WRK_MAT_F16 || KIND == WRK_MAT_Q6_K || KIND == WRK_MAT_Q8_0) ? 0 : u];
             f32x4v acc[NT], amin[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) { acc[t] = (f32x4v){0.f, 0.f, 0.f, 0.f}; amin[t] = (f32x4v){0.f, 0.f, 0.f, 0.f}; }
@@ -1508,6 +1539,7 @@ __global__ void __launch_bounds__(256) gemm_ks_kernel(const KsBatch B) {
         case WRK_MAT_Q4_K: gemm_ks_body<WRK_MAT_Q4_K, NT, BPS>(P, B.ks[ji], B.part, B.counters, lds, &sh_flag); break;
         case WRK_MAT_Q5_K: gemm_ks_body<WRK_MAT_Q5_K, NT, BPS>(P, B.ks[ji], B.part, B.counters, lds, &sh_flag); break;
         case WRK_MAT_Q6_K: gemm_ks_body<WRK_MAT_Q6_K, NT, BPS>(P, B.ks[ji], B.part, B.counters, lds, &sh_flag); break;
+        case WRK_MAT_Q8_0: gemm_ks_body<WRK_MAT_Q8_0, NT, BPS>(P, B.ks[ji], B.part, B.counters, lds, &sh_flag); break;
         default: gemm_ks_body<WRK_MAT_F16, NT, BPS>(P, B.ks[ji], B.part, B.counters, lds, &sh_flag); break;
     }
 }
@@ -1572,11 +1604,15 @@ static int launch_ks(hipStream_t s, const MatJob* jobs, int njobs, uint32_t n) {
     if (mode == 1 && n <= 16) {
         uint32_t tiles16 = 0, kmax = 0;
         for (int q = 0; q < njobs; ++q) { tiles16 += (jobs[q].m + 15) / 16; kmax = jobs[q].k > kmax ? jobs[q].k : kmax; }
-        if (!(tiles16 < 256 && kmax >= 4096)) return -1;
+        // round 3: long rows decide, not the tile count -- the RWKV-6 7B / 14B shapes (every K >= 4096, 256 .. 1 000 row tiles per launch):
+        // 16 streams of three 14B layers 0.800 ms with the K-split kernels, 0.632 with every launch K-sliced (profiles/r03_coverage_lines.jsonl)
+        (void)tiles16;
+        if (kmax < 4096) return -1;
     }
     for (int q = 0; q < njobs; ++q) {
         const MatJob& j = jobs[q];
-        if (j.kind != WRK_MAT_Q4_K && j.kind != WRK_MAT_Q5_K && j.kind != WRK_MAT_Q6_K && j.kind != WRK_MAT_F16) return -1;
+        if (j.kind != WRK_MAT_Q4_K && j.kind != WRK_MAT_Q5_K && j.kind != WRK_MAT_Q6_K && j.kind != WRK_MAT_Q8_0 && j.kind != WRK_MAT_F16) return -1;
+        if (j.kind == WRK_MAT_Q8_0 && (j.row_bytes & 15u)) return -1;       // the block scales of a slice are loaded as 16-byte vectors
         if ((j.k & 255u) || j.k < 256) return -1;
     }
     // blocks per slice: as many as still give every CU a workgroup (fewer slices = fewer partial tiles to add); the staged activation
@@ -1662,7 +1698,8 @@ int matmul_mfma_multi(hipStream_t s, const MatJob* jobs, int njobs, int) {
         // matrix x 128 tokens has only 64 tiles and is faster on the K-split kernel: 44 vs 74 us)
         const uint32_t tiles = ((j.m + TILE_ROWS - 1) / TILE_ROWS) * ((n + TILE_TOK - 1) / TILE_TOK);
         // (Q8_0 has a body in the second-generation tile kernel only: >= 512 tokens, K % 128 == 0, rows in fours)
-        const bool q8_tile2 = j.kind == WRK_MAT_Q8_0 && use_tile2 && n >= 512 && (j.k & 127u) == 0 && (j.m & 3u) == 0;
+        // (round 3: from 48 tokens on -- the first-generation tile has no Q8_0 body, and the K-split kernel re-reads the activations per 16 rows)
+        const bool q8_tile2 = j.kind == WRK_MAT_Q8_0 && use_tile2 && n >= 48 && (j.k & 127u) == 0 && (j.m & 3u) == 0;
         const bool tile = use_tile && n >= 48 && (j.kind == WRK_MAT_Q4_K || j.kind == WRK_MAT_Q5_K || j.kind == WRK_MAT_Q6_K || j.kind == WRK_MAT_F16 || q8_tile2) && j.m >= 64 &&
                           j.in.shape[2] == 1 && (tiles >= 96 || (j.k <= 2560 && tiles >= 64) ||    // enough workgroups, or a short serial walk,
                                                  (j.kind == WRK_MAT_F16 && j.k <= 2560));          // or a LoRA down-projection (64..320 rows): a handful of
@@ -1671,7 +1708,7 @@ int matmul_mfma_multi(hipStream_t s, const MatJob* jobs, int njobs, int) {
         // (with few workgroups -- a single 128-token chunk -- the first-generation kernel's longer stages are 4 % faster)
         static const bool f16_tile2_on = [] { const char* e = getenv("WRK_GEMM_TILE2_F16"); return !(e && e[0] == '0'); }();
         const bool f16_tile2 = f16_tile2_on && j.kind == WRK_MAT_F16 && (j.k & 127u) == 0 && (j.row_bytes & 15u) == 0;
-        if (tile && use_tile2 && n >= 512 && (j.kind == WRK_MAT_Q4_K || j.kind == WRK_MAT_Q5_K || q8_tile2 || f16_tile2) && (j.m & 3u) == 0) { fill_job(T2.jobs[T2.njobs++], j, n, t2wg); t2wg += (j.m + TILE_ROWS - 1) / TILE_ROWS; }
+        if (tile && use_tile2 && (n >= 512 || q8_tile2) && (j.kind == WRK_MAT_Q4_K || j.kind == WRK_MAT_Q5_K || q8_tile2 || f16_tile2) && (j.m & 3u) == 0) { fill_job(T2.jobs[T2.njobs++], j, n, t2wg); t2wg += (j.m + TILE_ROWS - 1) / TILE_ROWS; }
         else if (tile) { fill_job(T.jobs[T.njobs++], j, n, twg); twg += (j.m + TILE_ROWS - 1) / TILE_ROWS; }
         else { fill_job(B.jobs[B.njobs++], j, n, wg); wg += (j.m + 15) / 16; kmax = j.k > kmax ? j.k : kmax; }
     }

@@ -14,6 +14,7 @@ struct V6Scratch {
     void *input, *x, *aux_x, *att_x, *att_xx, *att_sx, *att_w, *att_g, *att_o, *tmx, *tmt, *tm, *ffn_x, *ffn_kx, *ffn_rx, *ffn_k, *ffn_v, *ffn_r, *head_x;
     float *att_k, *att_v, *att_r, *time_decay, *head_o;
     uint32_t *cursors, *tokens, *headers, *argmax, *counter;
+    float* ks_part; uint32_t* ks_cnt; size_t ks_part_cap; uint32_t ks_cnt_cap;     // K-sliced GEMM scratch (2 .. 32 sequences), see MatJob
 };
 
 struct wrk_v6_model {
@@ -54,9 +55,25 @@ int32_t wrk_v6_model::ensure_scratch(uint32_t T, uint32_t NH) {
     const size_t o_k = take(v32), o_v = take(v32), o_r = take(v32), o_td = take(v32);
     const size_t o_hx = take(D * nh * 2), o_ho = take(V * nh * 4);
     const size_t o_cur = take((size_t)nt * 4), o_tok = take((size_t)nt * 4), o_hdr = take((size_t)nh * 4), o_arg = take((size_t)nh * 4), o_cnt = take(256);
+    // K-sliced GEMM (decode batches; round 3, as wrk_v7_model::ensure_scratch): f32 partial tiles [row group][K slice][token][64 rows] of the
+    // largest launch of a layer (at most one slice per 256-block) and one arrival counter per row group
+    size_t ks_floats = 0, ks_groups = 0, o_ksp = 0, o_ksc = 0;
+    if (nt >= 2) {
+        const size_t ntp = nt <= 16 ? 16 : (nt <= 32 ? 32 : 64);
+        auto tiles = [](size_t m, size_t k) { return ((m + 63) / 64) * (k / 256 ? k / 256 : 1); };
+        auto groups = [](size_t m) { return (m + 63) / 64; };
+        const size_t k3 = 4 * tiles(D, D) + tiles(W, D), k6 = tiles(F, D) + tiles(D, D), k7 = tiles(D, F), k1 = tiles(5 * R, D);
+        const size_t most = std::max(std::max(k3, k6), std::max(k7, k1));
+        ks_floats = most * 64 * ntp;
+        ks_groups = 4 * groups(D) + groups(W) + groups(F) + groups(5 * R) + 8;
+        o_ksp = take(ks_floats * 4);
+        o_ksc = take(ks_groups * 4);
+    }
     WRK_HIP(ctx, hipMalloc(&scratch, off));
     WRK_HIP(ctx, hipMemsetAsync(scratch, 0, off, ctx->stream));
     char* b = (char*)scratch;
+    s.ks_part = ks_floats ? (float*)(b + o_ksp) : nullptr; s.ks_cnt = ks_floats ? (uint32_t*)(b + o_ksc) : nullptr;
+    s.ks_part_cap = ks_floats; s.ks_cnt_cap = (uint32_t)ks_groups;
     s.input = b + o_input; s.x = b + o_x; s.aux_x = b + o_aux; s.att_x = b + o_attx; s.att_xx = b + o_attxx; s.att_sx = b + o_sx;
     s.att_w = b + o_w; s.att_g = b + o_g; s.att_o = b + o_o; s.tmx = b + o_tmx; s.tmt = b + o_tmt; s.tm = b + o_tm;
     s.ffn_x = b + o_fx; s.ffn_kx = b + o_fkx; s.ffn_rx = b + o_frx; s.ffn_k = b + o_fk; s.ffn_v = b + o_fv; s.ffn_r = b + o_fr;
@@ -387,6 +404,7 @@ int32_t wrk_v6_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_
     auto vec = [&](void* p, uint32_t c = 0, uint32_t dt = WRK_F16) { return make_dense(p, dt, c ? c : D, T); };
     auto run_jobs = [&](wrk::MatJob* jobs, int n) -> int {
         if (T >= wrk::gemm_min_tokens()) {
+            jobs[0].ks_part = s.ks_part; jobs[0].ks_cnt = s.ks_cnt; jobs[0].ks_part_cap = s.ks_part_cap; jobs[0].ks_cnt_cap = s.ks_cnt_cap;
             if (wrk::matmul_mfma_multi(q, jobs, n, ctx->num_cu) == 0) return 0;
             for (int i = 0; i < n; ++i) {
                 int rc = wrk::matmul_mfma(q, jobs[i], ctx->num_cu);
@@ -398,6 +416,8 @@ int32_t wrk_v6_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_
         return wrk::matvec_grouped(q, jobs, n, ctx->num_cu);
     };
 #define LNMIX(P, n) do { if (wrk::ln_mix(q, P, n) != 0) return wrk_fail(ctx, WRK_E_UNSUPPORTED, "ln_mix shape"); } while (0)
+    // arrival counters of the K-sliced GEMM: zero at the head of every step (a launch that aborted must not poison the next replay)
+    if (T >= 2 && s.ks_cnt && s.ks_cnt_cap) WRK_HIP(ctx, hipMemsetAsync(s.ks_cnt, 0, (size_t)s.ks_cnt_cap * 4, q));
     {   // embedding rows (already gathered into s.input) -> LN0 -> x
         wrk::LnMixParams P{};
         P.src = (const f16*)s.input; P.ln_w = (const f16*)d.ln0_w->ptr; P.ln_b = (const f16*)d.ln0_b->ptr; P.eps = LN_EPS;
