@@ -15,15 +15,22 @@
 //     xsum_kernel, f32 split into hi + lo f16), A_min[row][s] = -dmin * m_s (17 significant bits: exact as hi + lo f16), and
 //     total += A_min . S as three MFMAs (hi.hi, hi.lo, lo.hi) per 1024 k and C tile: +9 % MFMAs instead of +100 %;
 //   * the main term is unchanged in value: A = q * sc (exact small integers in f16), accumulated per 256-block, total += d * acc in f32.
-// LDS: A 2 x 128 x 136 f16 + X 2 x 128 x 136 f16 + per-row d 2 x 128 f32 + A_min hi / lo 2 x 128 x 40 f16 = 157 KB: one workgroup (16 waves would
+// LDS: A 2 x 128 x 128 f16 + X 2 x 128 x 128 f16 (swizzled, see t3_off) + per-row d 2 x 128 f32 + A_min hi / lo 2 x 128 x 40 f16 = 149 KB: one workgroup (16 waves would
 // not fit the registers: 64 accumulator registers per wave) per CU, two waves per SIMD.
 #include <cstdlib>
+#include <type_traits>
 
 #include "wrk_gemm_dev.h"
 
 namespace wrk {
 
-constexpr int T3_ROWS = 128, T3_TOK = 128, T3_KH = 128, T3_LR = T3_KH + 8, T3_MR = 32 + 8;
+// LDS images of a half block, [128 rows][128 k] f16 = 256-byte rows WITHOUT padding: 16-byte chunk c of row r sits at chunk c ^ (r & 15).
+// ds_read_b128 is served in four groups of 16 lanes -- {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 -- so a fragment read
+// (lane = row r + 16 g, chunk 4 ks + g) puts rows {0-3, 12-15} at chunk 4 ks and rows 4-11 at chunk 4 ks + 1 into one group: with the
+// swizzle their slots are {r ^ 4 ks} and {(r ^ 1) ^ 4 ks}: all sixteen distinct.  The first build padded the rows by 16 bytes instead
+// (slot = r + g + 4 ks): rows 11 (g = 1) and 12 (g = 0) collide in every group -- 37 % of its LDS cycles were conflict cycles.
+constexpr int T3_ROWS = 128, T3_TOK = 128, T3_KH = 128, T3_LR = T3_KH, T3_MR = 32 + 8;
+__device__ __forceinline__ uint32_t t3_off(uint32_t row, uint32_t chunk) { return row * (uint32_t)T3_LR + ((chunk ^ (row & 15u)) << 3); }      // f16 elements
 constexpr size_t T3_LDS = (size_t)(2 * 128 * T3_LR + 2 * 128 * T3_LR) * 2 + 2 * 128 * 4 + (size_t)2 * 128 * T3_MR * 2;
 
 struct T3Batch {
@@ -55,38 +62,42 @@ __global__ void __launch_bounds__(256) xsum_kernel(const f16* __restrict__ x, ui
 
 struct T3W { u32x2 q[4]; u32x4 sm; uint32_t dd; };
 
-// Dequantise half HF (k = 128 HF .. +127) of block b of ONE 16-row tile (rows 16 * tile + r of the workgroup: a wave's own tile) into the A buffer; with
-// HF == 0 also the row's d and the block's min products.
+// Dequantise one 32-k piece (PC = 0 .. 3) of half HF (k = 128 HF .. +127) of a block of ONE 16-row tile (rows 16 * tile + r of the workgroup: a wave's own
+// tile) into the A image.  Pieces are issued BETWEEN the MFMA groups of the half that is being multiplied (round 3, second build: the unpacking
+// and the LDS stores of the next half run while the matrix pipe works through the current one instead of after it).
+template <int HF, int PC>
+__device__ __forceinline__ void t3_dequant_piece(const T3W& R, f16* __restrict__ dst) {     // dst: As + t3_off(16 tile + r, 4 PC + g)
+    constexpr int j = 2 * HF + (PC >> 1);
+    const u32x2 q = R.q[j];
+    const uint32_t v = R.sm[j];
+    if ((PC & 1) == 0) *(f16x8*)dst = mul8(codes8(q.x & 0x0f0f0f0fu, q.y & 0x0f0f0f0fu), (float)(v & 0xffu) * 1024.0f);            // q * sc * 2^-14, exact
+    else *(f16x8*)dst = mul8(codes8(q.x & 0xf0f0f0f0u, q.y & 0xf0f0f0f0u), (float)((v >> 8) & 0xffu) * 64.0f);
+}
+// the row's d and the block's min products (with the first half of a block)
+__device__ __forceinline__ void t3_dequant_meta(const T3W& R, uint32_t b, uint32_t nb, float* __restrict__ Dd, f16* __restrict__ Amh, f16* __restrict__ Aml,
+                                                uint32_t tile, uint32_t r, uint32_t g) {
+    const float d = (float)__builtin_bit_cast(f16, (uint16_t)(R.dd & 0xffffu)) * 16384.0f;
+    const float dmin = (float)__builtin_bit_cast(f16, (uint16_t)(R.dd >> 16));
+    if (g == 0) Dd[(b & 1u) * 128u + 16u * tile + r] = d;
+    // lane g: sub-blocks 2g, 2g + 1 of the block (the mins of 64-element group g)
+    const uint32_t v = g == 0 ? R.sm[0] : g == 1 ? R.sm[1] : g == 2 ? R.sm[2] : R.sm[3];
+    const float p0 = -(dmin * (float)((v >> 16) & 0xffu)), p1 = -(dmin * (float)(v >> 24));
+    const f16 h0 = (f16)p0, h1 = (f16)p1;
+    const f16x2 hh = {h0, h1}, ll = {(f16)(p0 - (float)h0), (f16)(p1 - (float)h1)};
+    const uint32_t col = (b & 3u) * 8u + 2u * g, rowo = (16u * tile + r) * T3_MR;
+    *(f16x2*)(Amh + rowo + col) = hh;
+    *(f16x2*)(Aml + rowo + col) = ll;
+    if (b + 1 == nb) {                      // last block: the rest of its group of four multiplies zeros
+        const f16x2 z = {(f16)0.0f, (f16)0.0f};
+        for (uint32_t bb = (b & 3u) + 1; bb < 4; ++bb) { *(f16x2*)(Amh + rowo + bb * 8u + 2u * g) = z; *(f16x2*)(Aml + rowo + bb * 8u + 2u * g) = z; }
+    }
+}
 template <int HF>
 __device__ __forceinline__ void t3_dequant(const T3W& R, uint32_t b, uint32_t nb, f16* __restrict__ As, float* __restrict__ Dd, f16* __restrict__ Amh,
                                            f16* __restrict__ Aml, uint32_t tile, uint32_t r, uint32_t g) {
-    f16* arow = As + (16u * tile + r) * T3_LR + 8u * g;
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
-        const int j = 2 * HF + jj;
-        const u32x2 q = R.q[j];
-        const uint32_t v = R.sm[j];
-        const float sc0 = (float)(v & 0xffu), sc1 = (float)((v >> 8) & 0xffu);
-        *(f16x8*)(arow + jj * 64) = mul8(codes8(q.x & 0x0f0f0f0fu, q.y & 0x0f0f0f0fu), sc0 * 1024.0f);          // q * sc * 2^-14, exact
-        *(f16x8*)(arow + jj * 64 + 32) = mul8(codes8(q.x & 0xf0f0f0f0u, q.y & 0xf0f0f0f0u), sc1 * 64.0f);
-    }
-    if (HF == 0) {
-        const float d = (float)__builtin_bit_cast(f16, (uint16_t)(R.dd & 0xffffu)) * 16384.0f;
-        const float dmin = (float)__builtin_bit_cast(f16, (uint16_t)(R.dd >> 16));
-        if (g == 0) Dd[(b & 1u) * 128u + 16u * tile + r] = d;
-        // lane g: sub-blocks 2g, 2g + 1 of the block (the mins of 64-element group g)
-        const uint32_t v = g == 0 ? R.sm[0] : g == 1 ? R.sm[1] : g == 2 ? R.sm[2] : R.sm[3];
-        const float p0 = -(dmin * (float)((v >> 16) & 0xffu)), p1 = -(dmin * (float)(v >> 24));
-        const f16 h0 = (f16)p0, h1 = (f16)p1;
-        const f16x2 hh = {h0, h1}, ll = {(f16)(p0 - (float)h0), (f16)(p1 - (float)h1)};
-        const uint32_t col = (b & 3u) * 8u + 2u * g, rowo = (16u * tile + r) * T3_MR;
-        *(f16x2*)(Amh + rowo + col) = hh;
-        *(f16x2*)(Aml + rowo + col) = ll;
-        if (b + 1 == nb) {                      // last block: the rest of its group of four multiplies zeros
-            const f16x2 z = {(f16)0.0f, (f16)0.0f};
-            for (uint32_t bb = (b & 3u) + 1; bb < 4; ++bb) { *(f16x2*)(Amh + rowo + bb * 8u + 2u * g) = z; *(f16x2*)(Aml + rowo + bb * 8u + 2u * g) = z; }
-        }
-    }
+    t3_dequant_piece<HF, 0>(R, As + t3_off(16u * tile + r, 0u + g)); t3_dequant_piece<HF, 1>(R, As + t3_off(16u * tile + r, 4u + g));
+    t3_dequant_piece<HF, 2>(R, As + t3_off(16u * tile + r, 8u + g)); t3_dequant_piece<HF, 3>(R, As + t3_off(16u * tile + r, 12u + g));
+    if (HF == 0) t3_dequant_meta(R, b, nb, Dd, Amh, Aml, tile, r, g);
 }
 
 // (A second build gave the waves ROLES -- waves 0-3 multiply 64 x 64 each, waves 4-7 only load / unpack / store the next half -- so that a
@@ -94,7 +105,7 @@ __device__ __forceinline__ void t3_dequant(const T3W& R, uint32_t b, uint32_t nb
 // not the split of the issue slots but what a CU can take in: 41 KB of activations + weights per 128-k half per CU for 4.2 MFLOP, and the
 // eight waves keep only ~64 KB of loads in flight against ~2 us of latency under load = ~18 GB/s per CU (the second-generation tile, with
 // three workgroups per CU, takes in 28 GB/s per CU at half the arithmetic intensity).  See DESIGN.md 4.2.)
-template <int DIAG>     // 0: product; diagnostics (WRK_T3_DIAG, wrong results): 1 no activation loads, 2 no weight loads / unpacking, 3 no MFMA
+template <int DIAG>     // 0: product; diagnostics (WRK_T3_DIAG; 1-3 wrong results): 1 no activation loads, 2 no weight loads / unpacking, 3 no MFMA, 4 cycle breakdown (printf)
 __global__ void __launch_bounds__(512) gemm_tile3_kernel(const T3Batch B) {
     extern __shared__ __attribute__((aligned(16))) unsigned char t3_smem[];
     int ji = 0;
@@ -126,24 +137,31 @@ __global__ void __launch_bounds__(512) gemm_tile3_kernel(const T3Batch B) {
         R.sm = *(const u32x4*)(wrow + soff + (size_t)b * 16);
         R.dd = *(const uint32_t*)(wrow + hoff + (size_t)b * 4);
     };
-    // activation staging: 128 tokens x 16 chunks of 8 f16 per half block; chunk c of a thread -> token (tid >> 4) + 32 c, columns 8 (tid & 15)
-    const f16* xsrc[4];
+    // activation staging (third build): LDS-DMA straight into the swizzled image, no staging registers and no LDS stores.  One
+    // global_load_lds_dwordx4 fills 1 KiB = four 256-byte rows, lane l -> row l >> 4, PHYSICAL chunk l & 15 -- so the lane fetches the logical
+    // chunk (l & 15) ^ (row & 15) of its token.  Wave w fills rows 16 w .. 16 w + 15 (four pieces) of the half's image.
+    typedef __attribute__((address_space(3))) unsigned char lds_u8;
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    lds_u8* xs_lds = (lds_u8*)t3_smem + (size_t)2 * 128 * T3_LR * 2;
+    const f16* xg[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) xsrc[c] = P.x + (size_t)min(n0 + (tid >> 4) + 32u * c, P.n - 1) * P.xs + (tid & 15u) * 8;
-    // the activations of a half are requested TWO halves before they are multiplied (one workgroup per CU: nothing else hides a global
-    // load's ~2 us under load)
-    f16x8 stage0[4], stage1[4];
+    for (int c = 0; c < 4; ++c) {
+        const uint32_t row = 16u * wave + 4u * c + (lane >> 4);
+        xg[c] = P.x + (size_t)min(n0 + row, P.n - 1) * P.xs + (((lane & 15u) ^ (row & 15u)) << 3);
+    }
     const uint32_t nhalf = 2 * nb;
-    auto fetch_x = [&](f16x8 (&stage)[4], uint32_t h) {
+    auto dma_x = [&](uint32_t h, uint32_t buf) {
+        if (DIAG == 1) return;
         const uint32_t hc = min(h, nhalf - 1);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) stage[c] = DIAG == 1 ? (f16x8){1, 1, 1, 1, 1, 1, 1, 1} : *(const f16x8*)(xsrc[c] + (size_t)hc * T3_KH);
+        for (int c = 0; c < 4; ++c)
+            __builtin_amdgcn_global_load_lds((gptr_t)(xg[c] + (size_t)hc * T3_KH), (__attribute__((address_space(3))) void*)(xs_lds + buf * (128u * T3_LR * 2u) + (16u * wave + 4u * c) * (T3_LR * 2u)), 16, 0, 0);
     };
-    auto store_x = [&](const f16x8 (&stage)[4], uint32_t buf) {
-        f16* base = Xs + (size_t)buf * 128 * T3_LR;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) *(f16x8*)(base + ((tid >> 4) + 32u * c) * T3_LR + (tid & 15u) * 8) = stage[c];
-    };
+    // swizzled LDS offsets (f16 elements), per lane: chunk (4 ks + g) ^ (r & 15) = 4 (ks ^ (r >> 2)) + (g ^ (r & 3)), and every row a lane touches
+    // in one image has the same r & 15 -- so an access is base + kof[ks] + an immediate
+    const uint32_t kof[4] = {((0u ^ (r >> 2)) << 5), ((1u ^ (r >> 2)) << 5), ((2u ^ (r >> 2)) << 5), ((3u ^ (r >> 2)) << 5)};
+    const uint32_t gl8 = (g ^ (r & 3u)) << 3;
+    const uint32_t a_base = (64u * wy + r) * T3_LR + gl8, x_base = (32u * wx + r) * T3_LR + gl8, d_base = (16u * wave + r) * T3_LR + gl8;
 
     f32x4v total[4][2], acc[4][2];
 #pragma unroll
@@ -166,30 +184,44 @@ __global__ void __launch_bounds__(512) gemm_tile3_kernel(const T3Batch B) {
 
     T3W W0, W1;
     load_w(W0, 0);
-    fetch_x(stage0, 0);
-    fetch_x(stage1, 1);
+    dma_x(0, 0);
     load_sums(0);
     t3_dequant<0>(W0, 0, nb, As, Dd, Amh, Aml, wave, r, g);
-    store_x(stage0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     // one half block: compute half (b, hf) out of buffers hf, produce the next half into buffers hf ^ 1
-    // (stage registers: half h + 1 sits in stage[hf ^ 1]; half h + 2 is requested into stage[hf], free since half h was stored)
+    // WRK_T3_DIAG=4: where a half goes, in shader cycles summed over the halves of one workgroup's wave 0 (printed by workgroup (0, 0))
+    unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tprev = 0;
+    auto tick = [&](int k) {
+        if (DIAG != 4) return;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        if (k >= 0) tacc[k] += now - tprev;
+        tprev = now;
+    };
+    tick(-1);
     auto half = [&](uint32_t b, int hf, const T3W& Rc, T3W& Rn) {
-        if (hf == 0) load_w(Rn, b + 1);
-        if (hf == 0) fetch_x(stage0, 2 * b + 2); else fetch_x(stage1, 2 * b + 3);
-        const f16* ab = As + (size_t)hf * 128 * T3_LR + (64u * wy + r) * T3_LR + 8u * g;
-        const f16* xb = Xs + (size_t)hf * 128 * T3_LR + (32u * wx + r) * T3_LR + 8u * g;
+        const f16* ab = As + (size_t)hf * 128 * T3_LR;
+        const f16* xb = Xs + (size_t)hf * 128 * T3_LR;
         // the fragments of step ks + 1 are read while step ks multiplies (two register sets; the compiler barriers keep the reads of a step
         // together and one step ahead -- left alone the scheduler waits for each step's reads right before its MFMAs: 23 waits per half)
         f16x8 fa[2][4], fb[2][2];
         auto frags = [&](int set, int ks) {
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt) fa[set][rt] = *(const f16x8*)(ab + rt * 16 * T3_LR + ks * 32);
+            for (int rt = 0; rt < 4; ++rt) fa[set][rt] = *(const f16x8*)(ab + a_base + kof[ks] + rt * 16 * T3_LR);
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt) fb[set][tt] = *(const f16x8*)(xb + tt * 16 * T3_LR + ks * 32);
+            for (int tt = 0; tt < 2; ++tt) fb[set][tt] = *(const f16x8*)(xb + x_base + kof[ks] + tt * 16 * T3_LR);
+        };
+        // one 32-k piece of the NEXT half (this wave's 16-row tile of weights, a quarter of its share of the activations) behind each MFMA group
+        const bool more = hf == 0 || b + 1 < nb;
+        auto produce = [&](auto pc) {
+            constexpr int PC = decltype(pc)::value;
+            if (hf == 0) t3_dequant_piece<1, PC>(Rc, As + (size_t)128 * T3_LR + d_base + kof[PC]);
+            else if (more) t3_dequant_piece<0, PC>(Rn, As + d_base + kof[PC]);
         };
         frags(0, 0);
+        tick(0);                // global loads and the first fragment reads issued (and, with the diagnostic's wait, the fragments arrived)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             asm volatile("" ::: "memory");
@@ -197,9 +229,24 @@ __global__ void __launch_bounds__(512) gemm_tile3_kernel(const T3Batch B) {
 #pragma unroll
             for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-                for (int tt = 0; tt < 2; ++tt) { if (DIAG == 3) acc[rt][tt][0] += (float)fa[ks & 1][rt][0] * (float)fb[ks & 1][tt][0]; else acc[rt][tt] = mfma16(fa[ks & 1][rt], fb[ks & 1][tt], acc[rt][tt]); }
+                for (int tt = 0; tt < 2; ++tt) {
+                    if (DIAG == 3) acc[rt][tt][0] += (float)fa[ks & 1][rt][0] * (float)fb[ks & 1][tt][0];
+                    else if (hf == 0 && ks == 0) acc[rt][tt] = mfma16(fa[0][rt], fb[0][tt], (f32x4v){0.f, 0.f, 0.f, 0.f});     // a block's first step: C = 0 (no zeroing pass)
+                    else acc[rt][tt] = mfma16(fa[ks & 1][rt], fb[ks & 1][tt], acc[rt][tt]);
+                }
+            if (ks == 0) {
+                // the global loads of the halves to come go out behind the first MFMA group (the first build issued them in front of the first
+                // fragment reads: ~800 cycles per half before the matrix pipe had anything to do)
+                if (hf == 0) load_w(Rn, b + 1);
+                dma_x(2 * b + hf + 1, (uint32_t)(hf ^ 1));        // the next half's activations: landed by the barrier that ends this half
+            }
+            if (ks == 0) produce(std::integral_constant<int, 0>{});
+            else if (ks == 1) produce(std::integral_constant<int, 1>{});
+            else if (ks == 2) produce(std::integral_constant<int, 2>{});
+            else produce(std::integral_constant<int, 3>{});
         }
         asm volatile("" ::: "memory");
+        tick(1);                // MFMA groups + the pieces of the next half
         if (hf == 0 && ((b & 3u) == 3u || b + 1 == nb)) {
             // the min term of this group of (up to) four blocks: A_min (LDS, complete since the last barrier) x the input sums
 #pragma unroll
@@ -223,15 +270,17 @@ __global__ void __launch_bounds__(512) gemm_tile3_kernel(const T3Batch B) {
                 for (int tt = 0; tt < 2; ++tt) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) total[rt][tt][i] = __builtin_fmaf(dv[i], acc[rt][tt][i], total[rt][tt][i]);
-                    acc[rt][tt] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+                    if (DIAG == 3) acc[rt][tt] = (f32x4v){0.f, 0.f, 0.f, 0.f};
                 }
             }
         }
-        // produce the next half
-        if (hf == 0) t3_dequant<1>(Rc, b, nb, As + (size_t)128 * T3_LR, Dd, Amh, Aml, wave, r, g);
-        else if (b + 1 < nb) t3_dequant<0>(Rn, b + 1, nb, As, Dd, Amh, Aml, wave, r, g);
-        if (hf == 0) store_x(stage1, 1u); else store_x(stage0, 0u);
+        // the next block's row scales and min products (its weights were unpacked piece by piece above)
+        if (hf == 1 && b + 1 < nb) t3_dequant_meta(Rn, b + 1, nb, Dd, Amh, Aml, wave, r, g);
+        tick(2);                // min term, block scales, meta
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's share of the next half's activations has landed
+        tick(3);
         __syncthreads();
+        tick(4);                // waiting for the other waves
     };
     for (uint32_t b = 0; b < nb; b += 2) {          // uniform over the workgroup
         half(b, 0, W0, W1);
@@ -241,6 +290,9 @@ __global__ void __launch_bounds__(512) gemm_tile3_kernel(const T3Batch B) {
         half(b + 1, 1, W1, W0);
     }
 
+    if (DIAG == 4 && blockIdx.x == 0 && blockIdx.y == 1 && tid == 0)
+        printf("[t3 diag] K %u halves %u | issue+first frags %llu | mfma+pieces %llu | min/scales %llu | drain %llu | barrier %llu (cycles, wave 0)\n", K, nhalf,
+               tacc[0], tacc[1], tacc[2], tacc[3], tacc[4]);
     // store: lane owns rows m0 + 64 wy + 16 rt + 4g + (0..3) of token n0 + 32 wx + 16 tt + r
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)
@@ -290,7 +342,7 @@ int gemm_tile3_launch(hipStream_t s, const GemmBatch& T3, uint32_t row_tiles, ui
     const int diag = de ? atoi(de) : 0;
     const dim3 grid(row_tiles, (n + T3_TOK - 1) / T3_TOK);
 #define T3_GO(D) do { if (!lds_attr_once((const void*)gemm_tile3_kernel<D>, T3_LDS)) return -1; gemm_tile3_kernel<D><<<grid, 512, T3_LDS, s>>>(B); } while (0)
-    if (diag == 1) T3_GO(1); else if (diag == 2) T3_GO(2); else if (diag == 3) T3_GO(3); else T3_GO(0);
+    if (diag == 1) T3_GO(1); else if (diag == 2) T3_GO(2); else if (diag == 3) T3_GO(3); else if (diag == 4) T3_GO(4); else T3_GO(0);
 #undef T3_GO
     return 0;
 }
