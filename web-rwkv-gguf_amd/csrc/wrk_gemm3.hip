@@ -100,6 +100,16 @@ __device__ __forceinline__ void t3_dequant(const T3W& R, uint32_t b, uint32_t nb
     if (HF == 0) t3_dequant_meta(R, b, nb, Dd, Amh, Aml, tile, r, g);
 }
 
+// Builds of round 3 and what WRK_T3_DIAG=4 (cycle counters of wave 0, summed over a workgroup's halves) says about them -- K = 8192, per 128-k half:
+//   first build (padded rows, unpacking + LDS stores behind the MFMAs)      32 x 128 prefill 110 k tok/s (with the quad WKV kernel)
+//   swizzled images + unpacking pieces between the MFMA groups               127.7 k: issue + first fragments 865 | MFMAs + pieces 1 273 | min term / block scales 758 |
+//                                                                            drain 156 | waiting at the barrier 1 330  = 4 380 cycles (the matrix pipe needs 1 024)
+//   + global loads behind the first MFMA group, C = 0 on a block's first step  127.0 k: 331 | 1 860 | 765 | 305 | 1 257: the time moved, the half did not get shorter
+//   + activations by LDS-DMA (no staging registers, no LDS stores for them)  124.9 k: 290 | 1 853 | 726 | 235 | 1 310 (225 registers instead of 253; not kept)
+// So a half costs ~4 400 cycles whatever is moved or removed: the two waves of a SIMD run the same phases at the same time (the barrier every
+// half re-aligns them), so one wave's vector work does not fill the other's matrix-pipe gaps, and wave 0 spends 30 % of a half waiting for
+// its SIMD partner.  What is left to try: block scales applied while the NEXT block multiplies (needs a second accumulator set: 257 registers
+// with the DMA build), or 256-k stages with single-buffered images (half as many barriers).
 // (A second build gave the waves ROLES -- waves 0-3 multiply 64 x 64 each, waves 4-7 only load / unpack / store the next half -- so that a
 // SIMD's matrix pipe and its vector pipe would be busy at the same time.  It was SLOWER: 304 vs 215 us per launch.  What bounds this kernel is
 // not the split of the issue slots but what a CU can take in: 41 KB of activations + weights per 128-k half per CU for 4.2 MFLOP, and the
@@ -137,31 +147,32 @@ __global__ void __launch_bounds__(512) gemm_tile3_kernel(const T3Batch B) {
         R.sm = *(const u32x4*)(wrow + soff + (size_t)b * 16);
         R.dd = *(const uint32_t*)(wrow + hoff + (size_t)b * 4);
     };
-    // activation staging (third build): LDS-DMA straight into the swizzled image, no staging registers and no LDS stores.  One
-    // global_load_lds_dwordx4 fills 1 KiB = four 256-byte rows, lane l -> row l >> 4, PHYSICAL chunk l & 15 -- so the lane fetches the logical
-    // chunk (l & 15) ^ (row & 15) of its token.  Wave w fills rows 16 w .. 16 w + 15 (four pieces) of the half's image.
-    typedef __attribute__((address_space(3))) unsigned char lds_u8;
-    typedef const __attribute__((address_space(1))) void* gptr_t;
-    lds_u8* xs_lds = (lds_u8*)t3_smem + (size_t)2 * 128 * T3_LR * 2;
-    const f16* xg[4];
+    // activation staging: 128 tokens x 16 chunks of 8 f16 per half block; chunk c of a thread -> token (tid >> 4) + 32 c, columns 8 (tid & 15)
+    const f16* xsrc[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const uint32_t row = 16u * wave + 4u * c + (lane >> 4);
-        xg[c] = P.x + (size_t)min(n0 + row, P.n - 1) * P.xs + (((lane & 15u) ^ (row & 15u)) << 3);
-    }
+    for (int c = 0; c < 4; ++c) xsrc[c] = P.x + (size_t)min(n0 + (tid >> 4) + 32u * c, P.n - 1) * P.xs + (tid & 15u) * 8;
+    // the activations of a half are requested TWO halves before they are multiplied (one workgroup per CU: nothing else hides a global
+    // load's ~2 us under load)
+    f16x8 stage0[4], stage1[4];
     const uint32_t nhalf = 2 * nb;
-    auto dma_x = [&](uint32_t h, uint32_t buf) {
-        if (DIAG == 1) return;
+    auto fetch_x = [&](f16x8 (&stage)[4], uint32_t h) {
         const uint32_t hc = min(h, nhalf - 1);
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-            __builtin_amdgcn_global_load_lds((gptr_t)(xg[c] + (size_t)hc * T3_KH), (__attribute__((address_space(3))) void*)(xs_lds + buf * (128u * T3_LR * 2u) + (16u * wave + 4u * c) * (T3_LR * 2u)), 16, 0, 0);
+        for (int c = 0; c < 4; ++c) stage[c] = DIAG == 1 ? (f16x8){1, 1, 1, 1, 1, 1, 1, 1} : *(const f16x8*)(xsrc[c] + (size_t)hc * T3_KH);
     };
     // swizzled LDS offsets (f16 elements), per lane: chunk (4 ks + g) ^ (r & 15) = 4 (ks ^ (r >> 2)) + (g ^ (r & 3)), and every row a lane touches
     // in one image has the same r & 15 -- so an access is base + kof[ks] + an immediate
     const uint32_t kof[4] = {((0u ^ (r >> 2)) << 5), ((1u ^ (r >> 2)) << 5), ((2u ^ (r >> 2)) << 5), ((3u ^ (r >> 2)) << 5)};
     const uint32_t gl8 = (g ^ (r & 3u)) << 3;
     const uint32_t a_base = (64u * wy + r) * T3_LR + gl8, x_base = (32u * wx + r) * T3_LR + gl8, d_base = (16u * wave + r) * T3_LR + gl8;
+    const uint32_t s_base = (tid >> 4) * T3_LR + (((tid & 15u) ^ ((tid >> 4) & 15u)) << 3);        // rows (tid >> 4) + 32 c: same row & 15
+    auto store_x1 = [&](const f16x8 (&stage)[4], uint32_t buf, int c) {
+        *(f16x8*)(Xs + (size_t)buf * 128 * T3_LR + s_base + (uint32_t)c * 32u * T3_LR) = stage[c];
+    };
+    auto store_x = [&](const f16x8 (&stage)[4], uint32_t buf) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) store_x1(stage, buf, c);
+    };
 
     f32x4v total[4][2], acc[4][2];
 #pragma unroll
@@ -184,13 +195,15 @@ __global__ void __launch_bounds__(512) gemm_tile3_kernel(const T3Batch B) {
 
     T3W W0, W1;
     load_w(W0, 0);
-    dma_x(0, 0);
+    fetch_x(stage0, 0);
+    fetch_x(stage1, 1);
     load_sums(0);
     t3_dequant<0>(W0, 0, nb, As, Dd, Amh, Aml, wave, r, g);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    store_x(stage0, 0);
     __syncthreads();
 
     // one half block: compute half (b, hf) out of buffers hf, produce the next half into buffers hf ^ 1
+    // (stage registers: half h + 1 sits in stage[hf ^ 1]; half h + 2 is requested into stage[hf], free since half h was stored)
     // WRK_T3_DIAG=4: where a half goes, in shader cycles summed over the halves of one workgroup's wave 0 (printed by workgroup (0, 0))
     unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tprev = 0;
     auto tick = [&](int k) {
@@ -219,6 +232,7 @@ __global__ void __launch_bounds__(512) gemm_tile3_kernel(const T3Batch B) {
             constexpr int PC = decltype(pc)::value;
             if (hf == 0) t3_dequant_piece<1, PC>(Rc, As + (size_t)128 * T3_LR + d_base + kof[PC]);
             else if (more) t3_dequant_piece<0, PC>(Rn, As + d_base + kof[PC]);
+            if (hf == 0) store_x1(stage1, 1u, PC); else store_x1(stage0, 0u, PC);
         };
         frags(0, 0);
         tick(0);                // global loads and the first fragment reads issued (and, with the diagnostic's wait, the fragments arrived)
@@ -238,7 +252,7 @@ __global__ void __launch_bounds__(512) gemm_tile3_kernel(const T3Batch B) {
                 // the global loads of the halves to come go out behind the first MFMA group (the first build issued them in front of the first
                 // fragment reads: ~800 cycles per half before the matrix pipe had anything to do)
                 if (hf == 0) load_w(Rn, b + 1);
-                dma_x(2 * b + hf + 1, (uint32_t)(hf ^ 1));        // the next half's activations: landed by the barrier that ends this half
+                if (hf == 0) fetch_x(stage0, 2 * b + 2); else fetch_x(stage1, 2 * b + 3);
             }
             if (ks == 0) produce(std::integral_constant<int, 0>{});
             else if (ks == 1) produce(std::integral_constant<int, 1>{});
@@ -277,8 +291,7 @@ __global__ void __launch_bounds__(512) gemm_tile3_kernel(const T3Batch B) {
         // the next block's row scales and min products (its weights were unpacked piece by piece above)
         if (hf == 1 && b + 1 < nb) t3_dequant_meta(Rn, b + 1, nb, Dd, Amh, Aml, wave, r, g);
         tick(2);                // min term, block scales, meta
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's share of the next half's activations has landed
-        tick(3);
+        if (DIAG == 4) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); tick(3); }     // everything this wave has in flight
         __syncthreads();
         tick(4);                // waiting for the other waves
     };
