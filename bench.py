@@ -35,7 +35,7 @@ HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 HBM_MEASURED_GBS = 6290.0   # float4 copy rate measured on MI355X (same guide, chip-level parameters)
 
 
-PMC_PROFILES = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")      # newest first
+PMC_PROFILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")      # newest first
 
 
 def measured_traffic(model, batch, mode):
@@ -517,7 +517,7 @@ def main():
                 out["prefill"] = prefill_leg(wrk, ctx, runtime, args.model, 1, 512, 128, mode=args.mode)
                 runtime.close()
                 rt32 = wrk.Runtime(ctx, reader, num_batch=32, weights=wrk.WEIGHTS_INLINE, quant=quant or None)      # cfg-3 regime: 32 prompts stacked
-                out["prefill_batched"] = prefill_leg(wrk, ctx, rt32, args.model, 32, 128, 32 * 128, repeats=3, warmups=1, mode=args.mode)     # one chunk of 4096 stacked tokens
+                out["prefill_batched"] = prefill_leg(wrk, ctx, rt32, args.model, 32, 128, 32 * 128, repeats=3, warmups=2, mode=args.mode)     # one chunk of 4096 stacked tokens
                 rt32.close()
                 runtime = None
             except Exception as e:      # a failing extra leg must not take the headline line with it

@@ -1601,13 +1601,20 @@ static int launch_ks(hipStream_t s, const MatJob* jobs, int njobs, uint32_t n) {
     const int mode = mode_env ? atoi(mode_env) : 1;
     if (mode <= 0 || !jobs[0].ks_part || !jobs[0].ks_cnt || n > 32) return -1;
     const int nt = n <= 16 ? 1 : 2;
+    bool all_q8 = false, any_other = false;
+    for (int q = 0; q < njobs; ++q) {
+        if (jobs[q].kind == WRK_MAT_Q8_0) all_q8 = true;
+        else if (jobs[q].kind != WRK_MAT_F16) any_other = true;
+    }
+    all_q8 = all_q8 && !any_other;
     if (mode == 1 && n <= 16) {
         uint32_t tiles16 = 0, kmax = 0;
         for (int q = 0; q < njobs; ++q) { tiles16 += (jobs[q].m + 15) / 16; kmax = jobs[q].k > kmax ? jobs[q].k : kmax; }
-        // round 3: long rows decide, not the tile count -- the RWKV-6 7B / 14B shapes (every K >= 4096, 256 .. 1 000 row tiles per launch):
-        // 16 streams of three 14B layers 0.800 ms with the K-split kernels, 0.632 with every launch K-sliced (profiles/r03_coverage_lines.jsonl)
-        (void)tiles16;
-        if (kmax < 4096) return -1;
+        // round 3 (tools/ks_v6_sweep.sh, three RWKV-6 layers with D = 4096, ms per step, K-split kernels | this kernel with 2 | 4 blocks per slice):
+        //   Q5_K x 16 streams 0.508 | 0.515 | 0.570, x 8 0.429 | - | 0.538        -> the K4 kinds keep the rule above
+        //   Q8_0 x 16 streams 0.808 | 0.542 | 0.631, x 8 0.725 | - | 0.605        -> Q8_0 launches always come here (the K-split kernel's Q8_0
+        //   body loads four row scales per 32-block and lane; here a slice's scales are one 16-byte load per row), two blocks per slice
+        if (!(all_q8 || (tiles16 < 256 && kmax >= 4096))) return -1;
     }
     for (int q = 0; q < njobs; ++q) {
         const MatJob& j = jobs[q];
@@ -1619,7 +1626,7 @@ static int launch_ks(hipStream_t s, const MatJob* jobs, int njobs, uint32_t n) {
     // slice (16 nt tokens x bps x 256) has to fit the default 64 KB of dynamic LDS
     static const int force_bps = [] { const char* e = getenv("WRK_KS_BPS"); return e ? atoi(e) : 0; }();
     int bps = 0;
-    for (int cand = 4; cand >= 1 && !bps; cand >>= 1) {
+    for (int cand = (all_q8 && !force_bps) ? 2 : 4; cand >= 1 && !bps; cand >>= 1) {
         if (nt * cand > 4) continue;
         if (force_bps && cand != force_bps) continue;
         bool div = true;
