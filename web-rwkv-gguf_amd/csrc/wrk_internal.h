@@ -148,7 +148,7 @@ void l2_norm(hipStream_t s, DTensor x, float eps);
 void token_shift(hipStream_t s, const uint32_t* cursors, DTensor mix, DTensor state, DTensor in, DTensor out, int reversed);
 // merged element-wise stages of an RWKV-7 layer over dense f16 [D, T] rows with 64-wide heads (bit-identical to the op chain)
 void pre_wkv_v7(hipStream_t s, void* w, void* a, void* k, void* v, void* vv, void* v0, void* n, const void* w0, const void* a0, const void* k_k,
-                const void* k_a, const void* v0p, uint32_t D, uint32_t T, bool first_layer, float l2_eps);
+                const void* k_a, const void* v0p, uint32_t D, uint32_t T, bool first_layer, float l2_eps, float* wdec = nullptr);
 void post_wkv_v7(hipStream_t s, void* x, const void* r, const void* g, const void* n, const void* gn_w, const void* gn_b, const void* r_k,
                  uint32_t D, uint32_t T, float gn_eps);
 // n <= 6 token_shift ops over the same input / state row in one pass (falls back to n launches for views it cannot vectorise)
@@ -162,7 +162,7 @@ void blit(hipStream_t s, DTensor in, DTensor out);
 void affine(hipStream_t s, DTensor x, float scale, float bias);
 void activate(hipStream_t s, DTensor x, uint32_t act);
 void control_k_v7(hipStream_t s, const void* p, DTensor a, DTensor k);
-void time_mix_v7(hipStream_t s, const uint32_t* cursors, DTensor state, DTensor r, DTensor w, DTensor n, DTensor x, uint32_t nseq_hint = 0);   // 0: unknown
+void time_mix_v7(hipStream_t s, const uint32_t* cursors, DTensor state, DTensor r, DTensor w, DTensor n, DTensor x, uint32_t nseq_hint = 0, const float* wdec = nullptr);   // nseq_hint 0: unknown; wdec: precomputed decays f32 [D, T] (pre_wkv_v7) or nullptr
 void time_first_v7(hipStream_t s, const void* u, DTensor r, DTensor n, DTensor x);
 void channel_mix_v7(hipStream_t s, const uint32_t* cursors, DTensor state, DTensor v, DTensor x);
 void softmax(hipStream_t s, DTensor x);

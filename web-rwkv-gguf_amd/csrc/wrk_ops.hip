@@ -421,14 +421,17 @@ __device__ __forceinline__ bool find_sequence(const uint32_t* __restrict__ curso
 // transcendentals per key channel) is prepared cooperatively: thread j < 64 computes w~[j] of the NEXT token into a
 // double-buffered LDS row, one barrier per token.  The f16 inputs of the next token are prefetched while the current
 // one is multiplied.  Measured (1.5B, 128-token chunk): 292 us -> see DESIGN.md.
-__global__ void __launch_bounds__(256) time_mix_v7_fast_kernel(const uint32_t* __restrict__ cursors, DTensor st, DTensor r, DTensor w,
-                                                                DTensor n, DTensor x, uint32_t ntok) {
-    constexpr int S = 64;
+// WD: the decays w~ come precomputed (f32 [T][D], written by pre_wkv_v7 from the same f16 w with the same expression): no LDS row, NO BARRIER
+// per token step -- the waves of a head run free (round 3; what a lone sequence's step costs is the chain, not the instruction count)
+template <int NP, bool WD>      // NP = threads per state column: 4 (16 rows each; round 2) or 8 (8 rows each: few sequences, see time_mix_v7)
+__global__ void __launch_bounds__(64 * NP) time_mix_v7_fast_kernel(const uint32_t* __restrict__ cursors, DTensor st, DTensor r, DTensor w,
+                                                                DTensor n, DTensor x, uint32_t ntok, const float* __restrict__ wdec) {
+    constexpr int S = 64, JJ = S / NP, NV = JJ / 8;
     __shared__ __attribute__((aligned(16))) float sh_w[2][S];
     const uint32_t head = blockIdx.x;
     Cursor cur;
     if (!find_sequence(cursors, ntok, blockIdx.y, cur)) return;       // fewer sequences in this dispatch than slots (uniform over the workgroup)
-    const uint32_t tid = threadIdx.x, i = tid >> 2, part = tid & 3u;
+    const uint32_t tid = threadIdx.x, i = tid / NP, part = tid % NP;
     const uint32_t ch = head * S + i;
     const uint32_t tend = cur.token + cur.len;
 
@@ -436,33 +439,38 @@ __global__ void __launch_bounds__(256) time_mix_v7_fast_kernel(const uint32_t* _
     if (part == 0) dt_store(st, dt_index(st, ch, 0, cur.batch), dt_load(x, dt_index(x, i, head, tend - 1)));
     // the state is f32 here (host-checked): plain loads, all sixteen in flight at once (dt_load branches on the element type, and the
     // compiler then waited vmcnt(0) after every one of them: sixteen serial round trips at the head of every chunk)
-    float Sreg[16];
+    float Sreg[JJ];
     float* sbase = (float*)st.p;
 #pragma unroll
-    for (int jj = 0; jj < 16; ++jj) Sreg[jj] = sbase[dt_index(st, ch, 1 + part * 16 + jj, cur.batch)];
+    for (int jj = 0; jj < JJ; ++jj) Sreg[jj] = sbase[dt_index(st, ch, 1 + part * JJ + jj, cur.batch)];
 
-    struct Tok { f16x8 r[2], k[2], a[2], kk[2]; f16 v; f16 wraw; };
+    struct Tok { f16x8 r[NV], k[NV], a[NV], kk[NV]; f16 v; f16 wraw; f32x4 wd[JJ / 4]; };
     // per-token pointers advance by constant strides (dense f16 views): no index arithmetic inside the loop
     const size_t rstep = (size_t)r.stride[1] * r.stride[0], nstep = (size_t)n.stride[1] * n.stride[0];
     const size_t wstep = (size_t)w.stride[1] * w.stride[0], xstep = (size_t)x.stride[1] * x.stride[0];
-    const f16* rp = (const f16*)r.p + dt_index(r, part * 16, head, cur.token);
-    const f16* kp = (const f16*)n.p + dt_index4(n, part * 16, head, cur.token, 0);
-    const f16* ap = (const f16*)n.p + dt_index4(n, part * 16, head, cur.token, 2);
-    const f16* qp = (const f16*)n.p + dt_index4(n, part * 16, head, cur.token, 3);
+    const f16* rp = (const f16*)r.p + dt_index(r, part * JJ, head, cur.token);
+    const f16* kp = (const f16*)n.p + dt_index4(n, part * JJ, head, cur.token, 0);
+    const f16* ap = (const f16*)n.p + dt_index4(n, part * JJ, head, cur.token, 2);
+    const f16* qp = (const f16*)n.p + dt_index4(n, part * JJ, head, cur.token, 3);
     const f16* vp = (const f16*)n.p + dt_index4(n, i, head, cur.token, 1);
     const f16* wp = (const f16*)w.p + dt_index(w, tid & 63u, head, cur.token);
+    const float* dp = (WD ? wdec : (const float*)st.p) + dt_index(w, part * JJ, head, cur.token);      // same [D, T] indexing as w (dense)
     f16* xp = (f16*)x.p + dt_index(x, i, head, cur.token);
     // Every load is unconditional (round 2): the predicated form (`if (more) load`, `if (tid < 64) wraw = *wp`) made the compiler wait
     // vmcnt(0) right behind the prefetch, so each token paid a full memory round trip (2.8 us per token in the 32 x 128 prefill).
     // The pointers stop advancing at the last token instead (`adv` = 0): its prefetch re-reads that token and is discarded.
     auto load_tok = [&](Tok& T, bool adv) {       // advances the pointers (unless at the end), then loads the token they stand on
         const size_t rs = adv ? rstep : 0, ns = adv ? nstep : 0, ws = adv ? wstep : 0;
-        rp += rs; kp += ns; ap += ns; qp += ns; vp += ns; wp += ws;
-        T.wraw = *wp;                               // first of its group: the decay of token t + 1 is needed one step before the rest
-        T.r[0] = *(const f16x8*)rp; T.r[1] = *(const f16x8*)(rp + 8);
-        T.k[0] = *(const f16x8*)kp; T.k[1] = *(const f16x8*)(kp + 8);
-        T.a[0] = *(const f16x8*)ap; T.a[1] = *(const f16x8*)(ap + 8);
-        T.kk[0] = *(const f16x8*)qp; T.kk[1] = *(const f16x8*)(qp + 8);
+        rp += rs; kp += ns; ap += ns; qp += ns; vp += ns; wp += ws; dp += ws;
+        if (WD) {
+#pragma unroll
+            for (int q = 0; q < JJ / 4; ++q) T.wd[q] = *(const f32x4*)(dp + 4 * q);
+        } else T.wraw = *wp;                               // first of its group: the decay of token t + 1 is needed one step before the rest
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            T.r[q] = *(const f16x8*)(rp + 8 * q); T.k[q] = *(const f16x8*)(kp + 8 * q);
+            T.a[q] = *(const f16x8*)(ap + 8 * q); T.kk[q] = *(const f16x8*)(qp + 8 * q);
+        }
         T.v = *vp;
     };
     // Tokens are requested NPF - 1 steps ahead: a ring of NPF register sets, the loop unrolled by NPF so every index is static, and NO
@@ -478,32 +486,33 @@ __global__ void __launch_bounds__(256) time_mix_v7_fast_kernel(const uint32_t* _
     load_tok(T[0], false);
 #pragma unroll
     for (int u = 1; u < NPF; ++u) { const bool adv = lpos + 1 < tend; load_tok(T[u], adv); lpos += adv ? 1u : 0u; }
-    if (tid < S) sh_w[cur.token & 1u][tid] = __expf(-0.606531f * act_sigmoid((float)T[0].wraw));
+    if (!WD && tid < S) sh_w[cur.token & 1u][tid] = __expf(-0.606531f * act_sigmoid((float)T[0].wraw));
     for (uint32_t tb = cur.token; tb < tend; tb += NPF) {
 #pragma unroll
         for (int u = 0; u < NPF; ++u) {
             const uint32_t t = tb + u;
             const bool valid = t < tend;                            // uniform; a masked step changes nothing
             const Tok& curT = T[u];
-            __syncthreads();                                        // w~ of token t is in sh_w[t & 1]
+            if (!WD) __syncthreads();                               // w~ of token t is in sh_w[t & 1]
             // w~ of the NEXT token goes into the other buffer right away (its decay arrived a step ago; the last token's again at the end
             // of the chunk): the exponentials of the one wave that computes it are off the path to the next barrier
-            if (tid < S) sh_w[(t + 1) & 1u][tid] = __expf(-0.606531f * act_sigmoid((float)T[(u + 1) % NPF].wraw));
-            const float* wt = sh_w[t & 1u] + part * 16;
-            float wv[16];
+            if (!WD && tid < S) sh_w[(t + 1) & 1u][tid] = __expf(-0.606531f * act_sigmoid((float)T[(u + 1) % NPF].wraw));
+            const float* wt = sh_w[t & 1u] + part * JJ;
+            float wv[JJ];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { const f32x4 v4 = *(const f32x4*)(wt + 4 * q); wv[4 * q] = v4[0]; wv[4 * q + 1] = v4[1]; wv[4 * q + 2] = v4[2]; wv[4 * q + 3] = v4[3]; }
+            for (int q = 0; q < JJ / 4; ++q) { const f32x4 v4 = WD ? curT.wd[q] : *(const f32x4*)(wt + 4 * q); wv[4 * q] = v4[0]; wv[4 * q + 1] = v4[1]; wv[4 * q + 2] = v4[2]; wv[4 * q + 3] = v4[3]; }
             // four independent FMA chains per reduction (a wave runs alone on its SIMD: latency, not issue, is the cost)
-            float kkf[16], s4[4] = {0.f, 0.f, 0.f, 0.f};
+            float kkf[JJ], s4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int jj = 0; jj < 16; ++jj) { kkf[jj] = (float)curT.kk[jj >> 3][jj & 7]; s4[jj & 3] = __builtin_fmaf(Sreg[jj], -kkf[jj], s4[jj & 3]); }   // a~ = -kk
+            for (int jj = 0; jj < JJ; ++jj) { kkf[jj] = (float)curT.kk[jj >> 3][jj & 7]; s4[jj & 3] = __builtin_fmaf(Sreg[jj], -kkf[jj], s4[jj & 3]); }   // a~ = -kk
             float sa = (s4[0] + s4[1]) + (s4[2] + s4[3]);
             sa = sa + dpp_f32<0xB1>(sa);          // lane ^ 1, lane ^ 2 inside the quad: DPP, not ds_bpermute (an LDS round trip each)
             sa = sa + dpp_f32<0x4E>(sa);
+            if (NP == 8) sa = sa + dpp_f32<0x141>(sa);      // the other quad of the column's eight lanes (row_half_mirror: lane i <-> 7 - i)
             const float vv = (float)curT.v;
             float y4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int jj = 0; jj < 16; ++jj) {
+            for (int jj = 0; jj < JJ; ++jj) {
                 const float kj = (float)curT.k[jj >> 3][jj & 7], aj = (float)curT.a[jj >> 3][jj & 7];
                 const float sn = Sreg[jj] * wv[jj] + kj * vv + sa * (kkf[jj] * aj);                                  // b~ = kk * a
                 Sreg[jj] = valid ? sn : Sreg[jj];
@@ -512,6 +521,7 @@ __global__ void __launch_bounds__(256) time_mix_v7_fast_kernel(const uint32_t* _
             float y = (y4[0] + y4[1]) + (y4[2] + y4[3]);
             y = y + dpp_f32<0xB1>(y);
             y = y + dpp_f32<0x4E>(y);
+            if (NP == 8) y = y + dpp_f32<0x141>(y);
             if (valid && part == 0) *xp = (f16)y;
             xp += valid ? xstep : 0;
             // this register set is free: request token t + NPF (the last token again once the chunk ends; discarded)
@@ -519,7 +529,7 @@ __global__ void __launch_bounds__(256) time_mix_v7_fast_kernel(const uint32_t* _
         }
     }
 #pragma unroll
-    for (int jj = 0; jj < 16; ++jj) sbase[dt_index(st, ch, 1 + part * 16 + jj, cur.batch)] = Sreg[jj];
+    for (int jj = 0; jj < JJ; ++jj) sbase[dt_index(st, ch, 1 + part * JJ + jj, cur.batch)] = Sreg[jj];
 }
 
 // v_fma_mix_f32 with an f16 operand taken from half HI of a dword, unconverted (plain asm: the compiler may move and drop them)
@@ -700,7 +710,7 @@ static bool dense_f16_heads(const DTensor& d) {
     return d.dtype == WRK_F16 && d.shape[0] == 64 && d.stride[0] == 64 && d.offset[0] == 0 && (((uintptr_t)d.p) & 15u) == 0;
 }
 
-void time_mix_v7(hipStream_t s, const uint32_t* cursors, DTensor st, DTensor r, DTensor w, DTensor n, DTensor x, uint32_t nseq_hint) {
+void time_mix_v7(hipStream_t s, const uint32_t* cursors, DTensor st, DTensor r, DTensor w, DTensor n, DTensor x, uint32_t nseq_hint, const float* wdec) {
     if (r.shape[2] == 0) return;
     const uint32_t H = r.shape[1], T = r.shape[2];
     if (dense_f16_heads(r) && dense_f16_heads(w) && dense_f16_heads(n) && dense_f16_heads(x) && st.dtype == WRK_F32) {
@@ -713,8 +723,13 @@ void time_mix_v7(hipStream_t s, const uint32_t* cursors, DTensor st, DTensor r, 
         const int force = fe ? atoi(fe) : -1;
         const bool wave = force >= 0 ? force != 0 : nseq * H >= 768;     // measured (1.5B, 32 heads): 16 sequences 110 k vs 107 k tok/s for four waves, 32 sequences 117 k vs 124 k
         dim3 grid(H, slots);
+        // few sequences (CUs idle): eight threads per state column instead of four -- half the instructions per wave and step, which is what a
+        // lone sequence's step costs (pp512: 0.69 -> see DESIGN 4.5); from 256 heads on every SIMD has a wave either way
+        const char* oe = getenv("WRK_WKV_OCT");
+        const bool oct = oe ? atoi(oe) != 0 : true;      // measured, x 32 heads: 1 / 4 / 8 / 16 sequences +3 / +2.4 / +2.3 / +2 % end to end over four threads per column
         if (wave) time_mix_v7_wave_kernel<<<grid, 64, 0, s>>>(cursors, st, r, w, n, x, T);
-        else time_mix_v7_fast_kernel<<<grid, 256, 0, s>>>(cursors, st, r, w, n, x, T);
+        else if (oct) { if (wdec) time_mix_v7_fast_kernel<8, true><<<grid, 512, 0, s>>>(cursors, st, r, w, n, x, T, wdec); else time_mix_v7_fast_kernel<8, false><<<grid, 512, 0, s>>>(cursors, st, r, w, n, x, T, nullptr); }
+        else { if (wdec) time_mix_v7_fast_kernel<4, true><<<grid, 256, 0, s>>>(cursors, st, r, w, n, x, T, wdec); else time_mix_v7_fast_kernel<4, false><<<grid, 256, 0, s>>>(cursors, st, r, w, n, x, T, nullptr); }
     } else {
         dim3 grid(H, T);
         time_mix_v7_kernel<<<grid, 256, 0, s>>>(cursors, st, r, w, n, x);
@@ -736,6 +751,7 @@ struct PreWkvParams {
     const f16 *w0, *a0, *k_k, *k_a, *v0p;
     uint32_t D, T, first_layer;
     float l2_eps;
+    float* wdec;                              // optional f32 [D, T]: w~ = exp(-0.606531 sigmoid(w)) of the stored (f16) w, for the chunk kernel
 };
 __global__ void __launch_bounds__(64) pre_wkv_v7_kernel(const PreWkvParams P) {
     const uint32_t head = blockIdx.x, t = blockIdx.y, c = head * 64 + threadIdx.x;
@@ -757,16 +773,17 @@ __global__ void __launch_bounds__(64) pre_wkv_v7_kernel(const PreWkvParams P) {
         vn = to_h(wgsl_mix((float)vn, (float)v0i, (float)f));
     }
     P.w[i] = wn;
+    if (P.wdec) P.wdec[i] = __expf(-0.606531f * act_sigmoid((float)wn));
     P.n[i] = kn;
     P.n[plane + i] = vn;
     P.n[2 * plane + i] = an;
     P.n[3 * plane + i] = kk1;
 }
 void pre_wkv_v7(hipStream_t s, void* w, void* a, void* k, void* v, void* vv, void* v0, void* n, const void* w0, const void* a0, const void* k_k,
-                const void* k_a, const void* v0p, uint32_t D, uint32_t T, bool first_layer, float l2_eps) {
+                const void* k_a, const void* v0p, uint32_t D, uint32_t T, bool first_layer, float l2_eps, float* wdec) {
     if (T == 0) return;
     PreWkvParams P{(f16*)w, (f16*)a, (f16*)k, (f16*)v, (f16*)vv, (f16*)v0, (f16*)n, (const f16*)w0, (const f16*)a0, (const f16*)k_k, (const f16*)k_a,
-                   (const f16*)v0p, D, T, first_layer ? 1u : 0u, l2_eps};
+                   (const f16*)v0p, D, T, first_layer ? 1u : 0u, l2_eps, wdec};
     pre_wkv_v7_kernel<<<dim3(D / 64, T), 64, 0, s>>>(P);
 }
 

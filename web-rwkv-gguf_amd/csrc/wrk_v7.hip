@@ -220,9 +220,11 @@ int32_t wrk_v7_model::enqueue_ops(wrk_v7_state* st, uint32_t T, uint32_t NH, boo
                 MM(L.v2, aux_v, vv, WRK_ACT_NONE);
             }
         }
+        float* wdec = (size_t)F * (act_dtype == WRK_F32 ? 4 : 2) >= (size_t)4 * D ? (float*)s.ffn_k : nullptr;
         if (m_pre) {     // steps 5-11's element-wise ops in one launch, bit-identical (wrk_ops.hip: pre_wkv_v7)
+            // (the decays of the chunk kernel ride along, f32 [D, T], in the ffn key buffer: 4 D values per token, free until the ffn key GEMM)
             wrk::pre_wkv_v7(q, s.w, s.a, s.k, s.v, s.vv, s.att_v0, s.n, L.w0->ptr, L.a0->ptr, L.k_k->ptr, L.k_a->ptr, li ? L.v0->ptr : L.a0->ptr,
-                            D, T, li == 0, L2_EPS);
+                            D, T, li == 0, L2_EPS, wdec);
         } else {
             wrk::binary(q, 0, bvec(L.w0), w, 0, 0, 0);                                       // 5
             wrk::binary(q, 0, bvec(L.a0), a, 0, 0, WRK_ACT_SIGMOID);                         // 6
@@ -241,7 +243,7 @@ int32_t wrk_v7_model::enqueue_ops(wrk_v7_state* st, uint32_t T, uint32_t NH, boo
             wrk::blit(q, a, nslice(2));
             wrk::blit(q, kk, nslice(3));
         }
-        wrk::time_mix_v7(q, s.cursors, st_att, heads(s.r), heads(s.w), n4, heads(s.att_x), wkv_nseq);   // 12
+        wrk::time_mix_v7(q, s.cursors, st_att, heads(s.r), heads(s.w), n4, heads(s.att_x), wkv_nseq, m_pre ? wdec : nullptr);   // 12
         if (m_post) wrk::post_wkv_v7(q, s.att_x, s.r, s.g, s.n, L.gn_w->ptr, L.gn_b->ptr, L.r_k->ptr, D, T, GN_EPS);    // 13-15 in one launch
         else {
             wrk::group_norm(q, L.gn_w->ptr, L.gn_b->ptr, heads(s.att_x), GN_EPS);        // 13
