@@ -1683,14 +1683,18 @@ int matmul_mfma_multi(hipStream_t s, const MatJob* jobs, int njobs, int) {
     GemmBatch T, B, Dq, T2, T3;
     T.njobs = B.njobs = Dq.njobs = T2.njobs = T3.njobs = 0;
     uint32_t twg = 0, wg = 0, kmax = 0, dwg = 0, t2wg = 0, t3wg = 0;
-    // third-generation prefill tile (wrk_gemm3.hip): Q4_K, >= 512 stacked tokens, the launch's sum scratch at hand.  WRK_GEMM_TILE3=0: off
+    // third-generation prefill tile (wrk_gemm3.hip): Q4_K, >= 128 stacked tokens, the launch's sum scratch at hand.  WRK_GEMM_TILE3=0: off
     // (read per call: the tests compare the kernels)
     const char* t3e = getenv("WRK_GEMM_TILE3");
-    const bool use_tile3 = !(t3e && t3e[0] == '0') && jobs[0].xsum != nullptr && n >= 512;
+    const bool use_tile3 = !(t3e && t3e[0] == '0') && jobs[0].xsum != nullptr && n >= 128;        // (round 3: from 128 tokens on, K split over workgroups for one or two token tiles)
     static const bool use_tile2 = [] { const char* e = getenv("WRK_GEMM_TILE2"); return !(e && e[0] == '0'); }();
     for (int q = 0; q < njobs; ++q) {
         const MatJob& j = jobs[q];
-        if (use_tile3 && j.kind == WRK_MAT_Q4_K && j.m >= 128 && j.in.shape[2] == 1 && (j.k & 255u) == 0 && T3.njobs < GEMM_MAX_JOBS) {
+        // below 512 tokens the tile runs K-split (wrk_gemm3.hip) and pays a sum pre-pass and a reduce launch: measured (1.5B, tokens/s, this tile |
+        // the kernels below): 128 tokens 21.5 k | 21.6 k with every matrix on it -- only the long rows gain (ffn value, K = 8192: 49.5 us -> 16 + 6.5 + 5);
+        // 256 tokens 38.9 k | 35.8 k; 384 tokens (three token tiles, no split) 37.8 k | 46.6 k
+        const bool t3_n = n >= 512 || (n > 128 && n <= 256) || (n == 128 && j.k >= 4096);
+        if (use_tile3 && t3_n && j.kind == WRK_MAT_Q4_K && j.m >= 128 && j.in.shape[2] == 1 && (j.k & 255u) == 0 && T3.njobs < GEMM_MAX_JOBS) {
             fill_job(T3.jobs[T3.njobs++], j, n, t3wg);
             t3wg += (j.m + 127) / 128;
             continue;

@@ -37,6 +37,11 @@ struct T3Batch {
     GemmBatch g;
     const f16* sh[GEMM_MAX_JOBS];       // input sums, high parts: [token][K / 32]
     const f16* sl[GEMM_MAX_JOBS];       // low parts
+    // K split over blockIdx.z (round 3: chunks of 128 .. 256 tokens -- one or two token tiles -- leave most CUs without a workgroup otherwise):
+    // slice z multiplies blocks [z bps, (z + 1) bps) and leaves an f32 partial tile [z][token][row]; t3_reduce_kernel adds them in slice order
+    uint32_t bps, kslices;              // kslices == 1: the whole K, epilogue in this kernel
+    float* part;
+    size_t poff[GEMM_MAX_JOBS];         // floats
 };
 
 // sums of the 32 inputs of every sub-block, f32, stored as hi + lo f16 (hi = round(s), lo = round(s - hi): 22 significant bits)
@@ -74,7 +79,7 @@ __device__ __forceinline__ void t3_dequant_piece(const T3W& R, f16* __restrict__
     else *(f16x8*)dst = mul8(codes8(q.x & 0xf0f0f0f0u, q.y & 0xf0f0f0f0u), (float)((v >> 8) & 0xffu) * 64.0f);
 }
 // the row's d and the block's min products (with the first half of a block)
-__device__ __forceinline__ void t3_dequant_meta(const T3W& R, uint32_t b, uint32_t nb, float* __restrict__ Dd, f16* __restrict__ Amh, f16* __restrict__ Aml,
+__device__ __forceinline__ void t3_dequant_meta(const T3W& R, uint32_t b, uint32_t nb /* end of the slice */, float* __restrict__ Dd, f16* __restrict__ Amh, f16* __restrict__ Aml,
                                                 uint32_t tile, uint32_t r, uint32_t g) {
     const float d = (float)__builtin_bit_cast(f16, (uint16_t)(R.dd & 0xffffu)) * 16384.0f;
     const float dmin = (float)__builtin_bit_cast(f16, (uint16_t)(R.dd >> 16));
@@ -136,6 +141,7 @@ __global__ void __launch_bounds__(512) gemm_tile3_kernel(const T3Batch B) {
     const uint32_t r = lane & 15, g = lane >> 4, wy = wave >> 2, wx = wave & 3u;
     const uint32_t m0 = (blockIdx.x - P.wg_begin) * T3_ROWS, n0 = blockIdx.y * T3_TOK;
     const uint32_t K = P.k, nb = K >> 8, nsub = K >> 5;
+    const uint32_t b_begin = B.kslices > 1 ? blockIdx.z * B.bps : 0u, b_end = B.kslices > 1 ? min(nb, b_begin + B.bps) : nb;
     // dequant role: rows m0 + 16 wave + r
     const uint8_t* wrow = P.w + (size_t)min(m0 + 16u * wave + r, P.m - 1) * P.row_bytes;
     const uint32_t hoff = nb * 128, soff = hoff + nb * 4;
@@ -194,11 +200,16 @@ __global__ void __launch_bounds__(512) gemm_tile3_kernel(const T3Batch B) {
     };
 
     T3W W0, W1;
-    load_w(W0, 0);
-    fetch_x(stage0, 0);
-    fetch_x(stage1, 1);
-    load_sums(0);
-    t3_dequant<0>(W0, 0, nb, As, Dd, Amh, Aml, wave, r, g);
+    load_w(W0, b_begin);
+    fetch_x(stage0, 2 * b_begin);
+    fetch_x(stage1, 2 * b_begin + 1);
+    load_sums(b_begin >> 2);
+    if (b_begin & 3u) {         // a slice that starts inside a group of four blocks: the blocks of the group in front of it multiply zeros
+        const f16x2 z = {(f16)0.0f, (f16)0.0f};
+        const uint32_t rowo = (16u * wave + r) * T3_MR;
+        for (uint32_t bb = 0; bb < (b_begin & 3u); ++bb) { *(f16x2*)(Amh + rowo + bb * 8u + 2u * g) = z; *(f16x2*)(Aml + rowo + bb * 8u + 2u * g) = z; }
+    }
+    t3_dequant<0>(W0, b_begin, b_end, As, Dd, Amh, Aml, wave, r, g);
     store_x(stage0, 0);
     __syncthreads();
 
@@ -227,7 +238,7 @@ __global__ void __launch_bounds__(512) gemm_tile3_kernel(const T3Batch B) {
             for (int tt = 0; tt < 2; ++tt) fb[set][tt] = *(const f16x8*)(xb + x_base + kof[ks] + tt * 16 * T3_LR);
         };
         // one 32-k piece of the NEXT half (this wave's 16-row tile of weights, a quarter of its share of the activations) behind each MFMA group
-        const bool more = hf == 0 || b + 1 < nb;
+        const bool more = hf == 0 || b + 1 < b_end;
         auto produce = [&](auto pc) {
             constexpr int PC = decltype(pc)::value;
             if (hf == 0) t3_dequant_piece<1, PC>(Rc, As + (size_t)128 * T3_LR + d_base + kof[PC]);
@@ -261,7 +272,7 @@ __global__ void __launch_bounds__(512) gemm_tile3_kernel(const T3Batch B) {
         }
         asm volatile("" ::: "memory");
         tick(1);                // MFMA groups + the pieces of the next half
-        if (hf == 0 && ((b & 3u) == 3u || b + 1 == nb)) {
+        if (hf == 0 && ((b & 3u) == 3u || b + 1 == b_end)) {
             // the min term of this group of (up to) four blocks: A_min (LDS, complete since the last barrier) x the input sums
 #pragma unroll
             for (int rt = 0; rt < 4; ++rt) {
@@ -289,16 +300,16 @@ __global__ void __launch_bounds__(512) gemm_tile3_kernel(const T3Batch B) {
             }
         }
         // the next block's row scales and min products (its weights were unpacked piece by piece above)
-        if (hf == 1 && b + 1 < nb) t3_dequant_meta(Rn, b + 1, nb, Dd, Amh, Aml, wave, r, g);
+        if (hf == 1 && b + 1 < b_end) t3_dequant_meta(Rn, b + 1, b_end, Dd, Amh, Aml, wave, r, g);
         tick(2);                // min term, block scales, meta
         if (DIAG == 4) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); tick(3); }     // everything this wave has in flight
         __syncthreads();
         tick(4);                // waiting for the other waves
     };
-    for (uint32_t b = 0; b < nb; b += 2) {          // uniform over the workgroup
+    for (uint32_t b = b_begin; b < b_end; b += 2) {          // uniform over the workgroup
         half(b, 0, W0, W1);
         half(b, 1, W0, W1);
-        if (b + 1 >= nb) break;
+        if (b + 1 >= b_end) break;
         half(b + 1, 0, W1, W0);
         half(b + 1, 1, W1, W0);
     }
@@ -313,6 +324,10 @@ __global__ void __launch_bounds__(512) gemm_tile3_kernel(const T3Batch B) {
         for (int tt = 0; tt < 2; ++tt) {
             const uint32_t tok = n0 + 32u * wx + 16u * tt + r, row = m0 + 64u * wy + 16u * rt + 4u * g;
             if (tok >= P.n || row >= P.m) continue;
+            if (B.kslices > 1) {        // this slice's share, f32, added up by t3_reduce_kernel
+                *(f32x4v*)(B.part + B.poff[ji] + ((size_t)blockIdx.z * P.n + tok) * P.m + row) = total[rt][tt];
+                continue;
+            }
             float o[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) o[i] = act_apply(P.act, total[rt][tt][i] * P.scale);
@@ -325,6 +340,37 @@ __global__ void __launch_bounds__(512) gemm_tile3_kernel(const T3Batch B) {
             if (P.out32) *(f32x4v*)((float*)P.out_p + oo) = (f32x4v){o[0], o[1], o[2], o[3]};
             else { typedef _Float16 f16x4 __attribute__((ext_vector_type(4))); *(f16x4*)((f16*)P.out_p + oo) = (f16x4){(f16)o[0], (f16)o[1], (f16)o[2], (f16)o[3]}; }
         }
+}
+
+// The slices of a split launch, added in slice order (deterministic), then the epilogue of the product: scale, activation, residual, store.
+// Thread = four rows of one token.
+__global__ void __launch_bounds__(256) t3_reduce_kernel(const T3Batch B, uint32_t total_quads) {
+    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= total_quads) return;
+    int ji = 0;
+    uint32_t base = 0;
+#pragma unroll
+    for (int q = 0; q + 1 < GEMM_MAX_JOBS; ++q) {
+        const uint32_t cnt = q < B.g.njobs ? (B.g.jobs[q].m >> 2) * B.g.jobs[q].n : 0u;
+        if (q + 1 < B.g.njobs && idx >= base + cnt && ji == q) { base += cnt; ji = q + 1; }
+    }
+    const GemmParams& P = B.g.jobs[ji];
+    const uint32_t local = idx - base, mq = P.m >> 2, tok = local / mq, row = (local - tok * mq) << 2;
+    const float* p = B.part + B.poff[ji] + (size_t)tok * P.m + row;
+    const size_t zs = (size_t)P.n * P.m;
+    f32x4v t = (f32x4v){0.f, 0.f, 0.f, 0.f};
+    for (uint32_t z = 0; z < B.kslices; ++z) t += *(const f32x4v*)(p + z * zs);
+    float o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = act_apply(P.act, t[i] * P.scale);
+    const size_t oo = (size_t)tok * P.os + row;
+    if (P.has_res) {
+        const size_t ro = (size_t)tok * P.rs + row;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = (P.out32 ? o[i] : r16(o[i])) + (P.res32 ? ((const float*)P.res_p)[ro + i] : (float)((const f16*)P.res_p)[ro + i]);
+    }
+    if (P.out32) *(f32x4v*)((float*)P.out_p + oo) = (f32x4v){o[0], o[1], o[2], o[3]};
+    else { typedef _Float16 f16x4 __attribute__((ext_vector_type(4))); *(f16x4*)((f16*)P.out_p + oo) = (f16x4){(f16)o[0], (f16)o[1], (f16)o[2], (f16)o[3]}; }
 }
 
 int gemm_tile3_launch(hipStream_t s, const GemmBatch& T3, uint32_t row_tiles, uint32_t n, void* xsum, size_t xsum_cap) {
@@ -351,12 +397,36 @@ int gemm_tile3_launch(hipStream_t s, const GemmBatch& T3, uint32_t row_tiles, ui
         xsum_kernel<<<dim3((uint32_t)((cnt + 255) / 256)), 256, 0, s>>>(P.x, P.xs, n, P.k >> 5, sh, sl);
     }
     (void)seen_x;
+    // K split: one or two token tiles and fewer than ~160 workgroups -> slices of 4, 2 or 1 blocks (the first that fills the chip), all jobs of the
+    // launch the same K.  Partial tiles behind the sum arrays in the launch's scratch.
+    const uint32_t ttiles = (n + T3_TOK - 1) / T3_TOK;
+    B.bps = 0; B.kslices = 1; B.part = nullptr;
+    {
+        bool same_k = true;
+        for (int q = 1; q < T3.njobs; ++q) same_k = same_k && T3.jobs[q].k == T3.jobs[0].k;
+        const uint32_t nb = T3.jobs[0].k >> 8;
+        const char* se = getenv("WRK_T3_SPLIT");        // 0: off (A/B)
+        if (same_k && ttiles <= 2 && row_tiles * ttiles < 160 && nb >= 2 && !(se && se[0] == '0')) {
+            uint32_t bps = 1;
+            for (uint32_t cand = 4; cand >= 1; cand >>= 1)
+                if (nb % cand == 0 && nb / cand >= 2 && row_tiles * ttiles * (nb / cand) >= 160) { bps = cand; break; }
+            const uint32_t ks = (nb + bps - 1) / bps;
+            size_t floats = 0, at = (used + 255) & ~(size_t)255;
+            for (int q = 0; q < T3.njobs; ++q) { B.poff[q] = floats; floats += (size_t)ks * n * T3.jobs[q].m; }
+            if (ks >= 2 && at + floats * 4 <= xsum_cap) { B.bps = bps; B.kslices = ks; B.part = (float*)((char*)xsum + at); }
+        }
+    }
     const char* de = getenv("WRK_T3_DIAG");
     const int diag = de ? atoi(de) : 0;
-    const dim3 grid(row_tiles, (n + T3_TOK - 1) / T3_TOK);
+    const dim3 grid(row_tiles, ttiles, B.kslices);
 #define T3_GO(D) do { if (!lds_attr_once((const void*)gemm_tile3_kernel<D>, T3_LDS)) return -1; gemm_tile3_kernel<D><<<grid, 512, T3_LDS, s>>>(B); } while (0)
     if (diag == 1) T3_GO(1); else if (diag == 2) T3_GO(2); else if (diag == 3) T3_GO(3); else if (diag == 4) T3_GO(4); else T3_GO(0);
 #undef T3_GO
+    if (B.kslices > 1) {
+        uint32_t quads = 0;
+        for (int q = 0; q < T3.njobs; ++q) quads += (T3.jobs[q].m >> 2) * n;
+        t3_reduce_kernel<<<dim3((quads + 255) / 256), 256, 0, s>>>(B, quads);
+    }
     return 0;
 }
 

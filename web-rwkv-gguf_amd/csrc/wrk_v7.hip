@@ -60,11 +60,13 @@ int32_t wrk_v7_model::ensure_scratch(uint32_t T, uint32_t NH) {
     }
     WRK_HIP(ctx, hipMalloc(&scratch, off));
     WRK_HIP(ctx, hipMemsetAsync(scratch, 0, off, ctx->stream));
-    if (nt >= 512 && act_dtype == WRK_F16) {
+    if (nt >= 128 && act_dtype == WRK_F16) {
         // prefill GEMM (wrk_gemm3.hip): sub-block input sums of the stacked tokens, hi + lo f16 per 32 inputs, for the up to three distinct
-        // inputs of a launch (r, k, v) or the F-wide ffn vector
+        // inputs of a launch (r, k, v) or the F-wide ffn vector; + the f32 partial tiles of K-split launches (chunks of up to 256 tokens:
+        // the widest launch, r / k / v or the ffn key, in two to four slices)
         const size_t widest = std::max<size_t>(3 * D, F);
-        const int32_t rs = wrk_ctx_reserve_gemm_scratch(ctx, (size_t)nt * (widest / 32) * 4 + 8 * 1024);
+        const size_t part = (size_t)256 * widest * 4 * 4;
+        const int32_t rs = wrk_ctx_reserve_gemm_scratch(ctx, (size_t)nt * (widest / 32) * 4 + 8 * 1024 + part);
         if (rs != WRK_OK) return rs;
     }
     char* b = (char*)scratch;
