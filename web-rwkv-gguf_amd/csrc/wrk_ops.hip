@@ -431,7 +431,7 @@ __global__ void __launch_bounds__(64 * NP) time_mix_v7_fast_kernel(const uint32_
     const uint32_t head = blockIdx.x;
     Cursor cur;
     if (!find_sequence(cursors, ntok, blockIdx.y, cur)) return;       // fewer sequences in this dispatch than slots (uniform over the workgroup)
-    const uint32_t tid = threadIdx.x, i = tid / NP, part = tid % NP;
+    const uint32_t tid = threadIdx.x, i = blockIdx.z * (blockDim.x / NP) + tid / NP, part = tid % NP;      // blockIdx.z: this workgroup's share of the head's 64 columns (WD only)
     const uint32_t ch = head * S + i;
     const uint32_t tend = cur.token + cur.len;
 
@@ -728,7 +728,16 @@ void time_mix_v7(hipStream_t s, const uint32_t* cursors, DTensor st, DTensor r, 
         const char* oe = getenv("WRK_WKV_OCT");
         const bool oct = oe ? atoi(oe) != 0 : true;      // measured, x 32 heads: 1 / 4 / 8 / 16 sequences +3 / +2.4 / +2.3 / +2 % end to end over four threads per column
         if (wave) time_mix_v7_wave_kernel<<<grid, 64, 0, s>>>(cursors, st, r, w, n, x, T);
-        else if (oct) { if (wdec) time_mix_v7_fast_kernel<8, true><<<grid, 512, 0, s>>>(cursors, st, r, w, n, x, T, wdec); else time_mix_v7_fast_kernel<8, false><<<grid, 512, 0, s>>>(cursors, st, r, w, n, x, T, nullptr); }
+        else if (oct && wdec) {
+            // The columns of a state are independent (sa_i, y_i never leave column i): with few sequences a head is dealt over 2 or 4 workgroups of
+            // 32 / 16 columns, so that its eight waves run on eight SIMDs of two or four CUs instead of two per SIMD of one (a lone sequence's
+            // step is issue-bound at two waves per SIMD: 0.47 us).  Every workgroup re-reads the per-row operands (r, k, a, kk, w~: L2 hits).
+            const char* ce = getenv("WRK_WKV_CSPLIT");
+            uint32_t cs = ce ? (uint32_t)atoi(ce) : (nseq * H <= 32 ? 4u : (nseq * H <= 128 ? 2u : 1u));      // measured (x 32 heads, tokens/s, 1 | 2 | 4 workgroups per head): 1 sequence 23.7 | 25.6 | 25.7 k, 2: 38.9 | 41.2 | 41.0 k, 4: 48.1 | 50.8 | 49.1 k, 8: 82.0 | 82.1 k
+            if (cs != 2 && cs != 4) cs = 1;
+            time_mix_v7_fast_kernel<8, true><<<dim3(H, slots, cs), 512 / cs, 0, s>>>(cursors, st, r, w, n, x, T, wdec);
+        }
+        else if (oct) time_mix_v7_fast_kernel<8, false><<<grid, 512, 0, s>>>(cursors, st, r, w, n, x, T, nullptr);
         else { if (wdec) time_mix_v7_fast_kernel<4, true><<<grid, 256, 0, s>>>(cursors, st, r, w, n, x, T, wdec); else time_mix_v7_fast_kernel<4, false><<<grid, 256, 0, s>>>(cursors, st, r, w, n, x, T, nullptr); }
     } else {
         dim3 grid(H, T);
