@@ -923,18 +923,19 @@ __global__ void __launch_bounds__(256) time_mix_v6_kernel(const uint32_t* __rest
 // owns S[16 part .. +15][i]; the reduction over j is 16 in-register FMAs + two quad shuffles, so a token needs no LDS and
 // no barrier at all (the generic kernel above spends four barriers per token).  Next token's operands are prefetched.
 __global__ void __launch_bounds__(256) time_mix_v6_fast_kernel(const uint32_t* __restrict__ cursors, DTensor decay, const float* __restrict__ u,
-                                                                DTensor st, DTensor k, DTensor v, DTensor r, DTensor x) {
+                                                                DTensor st, DTensor k, DTensor v, DTensor r, DTensor x, uint32_t ntok) {
     constexpr int S = 64;
-    const uint32_t head = blockIdx.x, t0 = blockIdx.y;
-    const Cursor cur = unpack_cursor(cursors[t0]);
-    if (cur.token != t0) return;
+    const uint32_t head = blockIdx.x;
+    Cursor cur;
+    if (!find_sequence(cursors, ntok, blockIdx.y, cur)) return;       // launched over (head, sequence slot), as the RWKV-7 chunk kernels (round 3)
     const uint32_t tid = threadIdx.x, i = tid >> 2, part = tid & 3u;
     const uint32_t ch = head * S + i;
     const uint32_t tend = cur.token + cur.len;
     if (part == 0) dt_store(st, dt_index(st, ch, 0, cur.batch), dt_load(x, dt_index(x, i, head, tend - 1)));
     float Sreg[16], uu[16];
+    float* sbase = (float*)st.p;         // f32 state (host-checked): plain loads, all in flight at once
 #pragma unroll
-    for (int jj = 0; jj < 16; ++jj) { Sreg[jj] = dt_load(st, dt_index(st, ch, 1 + part * 16 + jj, cur.batch)); uu[jj] = u[head * S + part * 16 + jj]; }
+    for (int jj = 0; jj < 16; ++jj) { Sreg[jj] = sbase[dt_index(st, ch, 1 + part * 16 + jj, cur.batch)]; uu[jj] = u[head * S + part * 16 + jj]; }
     struct Tok { f32x4 r[4], k[4], w[4]; float v; };
     const size_t rstep = (size_t)r.stride[1] * r.stride[0], kstep = (size_t)k.stride[1] * k.stride[0];
     const size_t wstep = (size_t)decay.stride[1] * decay.stride[0], vstep = (size_t)v.stride[1] * v.stride[0], xstep = (size_t)x.stride[1] * x.stride[0];
@@ -943,33 +944,45 @@ __global__ void __launch_bounds__(256) time_mix_v6_fast_kernel(const uint32_t* _
     const float* wp = (const float*)decay.p + dt_index(decay, part * 16, head, cur.token);
     const float* vp = (const float*)v.p + dt_index(v, i, head, cur.token);
     f16* xp = (f16*)x.p + dt_index(x, i, head, cur.token);
-    auto load_tok = [&](Tok& T) {
+    // As the RWKV-7 kernel (round 3; this one still had the round-1 form): every load unconditional -- the pointers stop at the last token --,
+    // a ring of NPF register sets with static indices (`if (more) load`, `cur = next` each cost a wait for everything in flight per token),
+    // steps beyond the chunk masked.
+    uint32_t lpos = cur.token;
+    auto load_tok = [&](Tok& T, bool adv) {
+        rp += adv ? rstep : 0; kp += adv ? kstep : 0; wp += adv ? wstep : 0; vp += adv ? vstep : 0;
+        lpos += adv ? 1u : 0u;
 #pragma unroll
         for (int q = 0; q < 4; ++q) { T.r[q] = *(const f32x4*)(rp + 4 * q); T.k[q] = *(const f32x4*)(kp + 4 * q); T.w[q] = *(const f32x4*)(wp + 4 * q); }
         T.v = *vp;
-        rp += rstep; kp += kstep; wp += wstep; vp += vstep;
     };
-    Tok curT, nxtT;
-    load_tok(curT);
-    for (uint32_t t = cur.token; t < tend; ++t) {
-        const bool more = t + 1 < tend;
-        if (more) load_tok(nxtT);
-        const float vv = curT.v;
-        float y = 0.0f;
+    constexpr int NPF = 3;
+    Tok T[NPF];
+    load_tok(T[0], false);
 #pragma unroll
-        for (int jj = 0; jj < 16; ++jj) {
-            const float kv = curT.k[jj >> 2][jj & 3] * vv;
-            y += curT.r[jj >> 2][jj & 3] * __builtin_fmaf(uu[jj], kv, Sreg[jj]);
-            Sreg[jj] = __builtin_fmaf(curT.w[jj >> 2][jj & 3], Sreg[jj], kv);
+    for (int q = 1; q < NPF; ++q) load_tok(T[q], lpos + 1 < tend);
+    for (uint32_t tb = cur.token; tb < tend; tb += NPF) {
+#pragma unroll
+        for (int q = 0; q < NPF; ++q) {
+            const bool valid = tb + q < tend;           // uniform; a masked step changes nothing
+            const Tok& curT = T[q];
+            const float vv = curT.v;
+            float y = 0.0f;
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) {
+                const float kv = curT.k[jj >> 2][jj & 3] * vv;
+                y += curT.r[jj >> 2][jj & 3] * __builtin_fmaf(uu[jj], kv, Sreg[jj]);
+                const float sn = __builtin_fmaf(curT.w[jj >> 2][jj & 3], Sreg[jj], kv);
+                Sreg[jj] = valid ? sn : Sreg[jj];
+            }
+            y = y + dpp_f32<0xB1>(y);
+            y = y + dpp_f32<0x4E>(y);
+            if (valid && part == 0) *xp = (f16)y;
+            xp += valid ? xstep : 0;
+            load_tok(T[q], lpos + 1 < tend);            // this register set is free: token t + NPF (the last one again beyond the chunk; discarded)
         }
-        y = y + dpp_f32<0xB1>(y);
-        y = y + dpp_f32<0x4E>(y);
-        if (part == 0) *xp = (f16)y;
-        xp += xstep;
-        if (more) curT = nxtT;
     }
 #pragma unroll
-    for (int jj = 0; jj < 16; ++jj) dt_store(st, dt_index(st, ch, 1 + part * 16 + jj, cur.batch), Sreg[jj]);
+    for (int jj = 0; jj < 16; ++jj) sbase[dt_index(st, ch, 1 + part * 16 + jj, cur.batch)] = Sreg[jj];
 }
 
 static bool dense_f32_heads(const DTensor& d) {
@@ -980,7 +993,8 @@ void time_mix_v6(hipStream_t s, const uint32_t* cursors, DTensor decay, const vo
     if (r.shape[2] == 0) return;
     dim3 grid(r.shape[1], r.shape[2]);
     if (dense_f32_heads(decay) && dense_f32_heads(k) && dense_f32_heads(v) && dense_f32_heads(r) && dense_f16_heads(x) && st.dtype == WRK_F32) {
-        time_mix_v6_fast_kernel<<<grid, 256, 0, s>>>(cursors, decay, (const float*)u, st, k, v, r, x);
+        const uint32_t T = r.shape[2], slots = std::min(T, st.shape[2]);       // at most one sequence per batch of the state and per token
+        time_mix_v6_fast_kernel<<<dim3(r.shape[1], slots), 256, 0, s>>>(cursors, decay, (const float*)u, st, k, v, r, x, T);
         return;
     }
     time_mix_v6_kernel<<<grid, 256, 0, s>>>(cursors, decay, (const float*)u, st, k, v, r, x);
