@@ -117,6 +117,30 @@ def test_gemm_matches_oracle(ctx, kind, k, m, T, B):
     assert np.all(np.abs(got - want) <= bound), np.abs(got - want).max()
 
 
+@pytest.mark.parametrize("kind,k,m", [("Q4_K", 512, 6416), ("Q5_K", 256, 6500), ("F16", 256, 6416), ("Q4_K", 2048, 8192)])
+@pytest.mark.parametrize("T", [5, 16])
+def test_gemm_two_row_tiles_per_workgroup(ctx, kind, k, m, T, monkeypatch):
+    """Round 3: launches of >= 400 row tiles at <= 16 tokens multiply two 16-row tiles per workgroup with the same B fragments
+    (gemm_pair_kernel): ragged last pair (6416 = 200 pairs + one tile, 6500 = rows in fours), against the oracle and bit-identical to the
+    one-tile kernel (same per-wave block order, same combine order)."""
+    raw = make(kind, k, m, k + m)
+    mat = wrk.Matrix(ctx, kind, k, m, raw)
+    w = dq.dequantize(kind, raw, k * m, round_f16=False).reshape(m, k)
+    x = np.random.default_rng(T).standard_normal((1, T, k)).astype(np.float16)
+    res = np.random.default_rng(T + 1).standard_normal((1, T, m)).astype(np.float16)
+    got = {}
+    for pair in ("1", "0"):
+        monkeypatch.setenv("WRK_GEMM_PAIR", pair)
+        out = ctx.zeros([m, T, 1], np.float32)
+        mat.matmul_op(ctx.tensor(x), out, turbo=True)
+        got[pair] = out.back().reshape(T, m)
+    want = x[0].astype(np.float64) @ w.astype(np.float64).T
+    bound = 4e-6 * (np.abs(x[0]).astype(np.float64) @ np.abs(w).astype(np.float64).T) + 1e-6
+    assert np.all(np.abs(got["1"] - want) <= bound), np.abs(got["1"] - want).max()
+    assert np.array_equal(got["1"], got["0"])
+    del res
+
+
 def test_gemm_activation_residual_f16_out_and_vec_agreement(ctx):
     k, m, T = 512, 72, 48
     raw = make("Q4_K", k, m, 5)

@@ -60,15 +60,20 @@ __device__ __forceinline__ void load_residual(const GemmParams& P, uint32_t n0, 
 // the outstanding loads and waits `vmcnt(0)` in front of every use -- the ISA had one full memory round trip per 256-block.
 // Tensors are dense token stacks (checked on the host): token tok of the input / output / residual is `tok * stride`
 // elements from the base.
-template <int KIND, int NT, int NW>
-__device__ __forceinline__ void gemm_body(const GemmParams& P, float (*sh_tot)[NT][4][64]) {
+// NR (round 3): row tiles per workgroup.  With 16 tokens every 16-row workgroup pulls the whole activation stack (64 KB) next to 18 KB of weights;
+// NR = 2 multiplies two row tiles with the same B fragments (K4 kinds and F16 only).  An experiment that lost (see the launch site): off by default.
+template <int KIND, int NT, int NW, int NR = 1>
+__device__ __forceinline__ void gemm_body(const GemmParams& P, float (*sh_tot)[NR * NT][4][64]) {
+    static_assert(NR == 1 || KIND == WRK_MAT_Q4_K || KIND == WRK_MAT_Q5_K || KIND == WRK_MAT_F16, "two row tiles: K4 kinds and F16");
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t r = lane & 15, g = lane >> 4;
-    const uint32_t m0 = (blockIdx.x - P.wg_begin) * 16;
+    const uint32_t m0 = (blockIdx.x - P.wg_begin) * 16 * NR;
     WRK_STAMP(P.dbg, 0);
-    const uint32_t row = min(m0 + r, P.m - 1);
-    const uint8_t* wrow = P.w + (size_t)row * P.row_bytes;
+    const uint8_t* wrows[NR];
+#pragma unroll
+    for (int rt = 0; rt < NR; ++rt) wrows[rt] = P.w + (size_t)min(m0 + 16u * rt + r, P.m - 1) * P.row_bytes;
+    const uint8_t* wrow = wrows[0];
     const uint32_t n0 = blockIdx.y * 16 * NT;
     const uint32_t K = P.k, nb = K >> 8;
 
@@ -78,35 +83,43 @@ __device__ __forceinline__ void gemm_body(const GemmParams& P, float (*sh_tot)[N
     for (int t = 0; t < NT; ++t) xrow[t] = P.x + (size_t)min(n0 + 16 * t + r, P.n - 1) * P.xs + 8 * g;
     auto loadB = [&](int t, uint32_t koff) -> f16x8 { return *(const f16x8*)(xrow[t] + koff); };
 
-    f32x4v total[NT];
+    f32x4v totals[NR][NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) total[t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+    for (int rt = 0; rt < NR; ++rt)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) totals[rt][t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+    f32x4v (&total)[NT] = totals[0];
 
     // residual operands of the C elements this lane stores (wave 0 does the epilogue): raw bits, requested with the first weights
-    uint32_t resb[NT][4];
+    uint32_t resbs[NR][NT][4];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int rt = 0; rt < NR; ++rt) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) resb[t][i] = 0;
-    load_residual<NT>(P, n0, m0, r, g, resb);
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) resbs[rt][t][i] = 0;
+        load_residual<NT>(P, n0, m0 + 16u * rt, r, g, resbs[rt]);
+    }
 
     if (KIND == WRK_MAT_F16) {
         // this wave's 32-k steps are wave, wave + NW, ...; FB steps' fragments are requested together.  Steps beyond K are
         // clamped to the last full fragment and their A fragment zeroed (a select, not a branch).
-        const f16* wr = (const f16*)wrow;
         constexpr int FB = 8;
         const uint32_t nsteps = (K + 31) >> 5, iters = (nsteps + NW - 1) / NW;
         const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
         const uint32_t klast = K - 8;
         for (uint32_t i0 = 0; i0 < iters; i0 += FB) {
-            f16x8 a[FB], bf[NT <= 2 ? NT : 1][FB];
+            f16x8 a[NR][FB], bf[NT <= 2 ? NT : 1][FB];
 #pragma unroll
             for (int u = 0; u < FB; ++u) {
                 const uint32_t k0 = 32 * (wave + NW * (i0 + u)) + 8 * g;
                 const bool ok = i0 + u < iters && k0 + 8 <= K;
                 const uint32_t kc = min(k0, klast);
-                const f16x8 av = *(const f16x8*)(wr + kc);
-                a[u] = ok ? av : zero8;
+#pragma unroll
+                for (int rt = 0; rt < NR; ++rt) {
+                    const f16x8 av = *(const f16x8*)((const f16*)wrows[rt] + kc);
+                    a[rt][u] = ok ? av : zero8;
+                }
                 if (NT <= 2) {
 #pragma unroll
                     for (int t = 0; t < (NT <= 2 ? NT : 1); ++t) bf[t][u] = *(const f16x8*)(xrow[t] - 8 * g + kc);
@@ -118,7 +131,8 @@ __device__ __forceinline__ void gemm_body(const GemmParams& P, float (*sh_tot)[N
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     const f16x8 bfr = NT <= 2 ? bf[NT <= 2 ? t : 0][u] : *(const f16x8*)(xrow[t] - 8 * g + kc);
-                    total[t] = mfma16(a[u], bfr, total[t]);
+#pragma unroll
+                    for (int rt = 0; rt < NR; ++rt) totals[rt][t] = mfma16(a[rt][u], bfr, totals[rt][t]);
                 }
             }
         }
@@ -309,16 +323,23 @@ __device__ __forceinline__ void gemm_body(const GemmParams& P, float (*sh_tot)[N
             uint32_t dd[4];         // (d, dmin) of the four C rows this lane owns
         };
         struct BBlk { f16x8 bf[NT <= 2 ? NT : 1][8]; };   // B fragments of the eight 32-k sub-blocks
-        const uint8_t* crow[4];
+        const uint8_t* crows[NR][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) crow[i] = P.w + (size_t)min(m0 + 4 * g + i, P.m - 1) * P.row_bytes + hoff;
-        auto load_w = [&](WBlk& R, uint32_t b) {
+        for (int rt = 0; rt < NR; ++rt)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) R.q[j] = *(const u32x2*)(wrow + (size_t)b * 128 + j * 32 + 8 * g);
-            if (KIND == WRK_MAT_Q5_K) R.qh = *(const u32x2*)(wrow + (size_t)nb * 128 + (size_t)b * 32 + 8 * g);
-            R.sm = *(const u32x4*)(wrow + soff + (size_t)b * 16);
+            for (int i = 0; i < 4; ++i) crows[rt][i] = P.w + (size_t)min(m0 + 16u * rt + 4 * g + i, P.m - 1) * P.row_bytes + hoff;
+        auto load_w1 = [&](WBlk& R, uint32_t b, int rt) {
+            const uint8_t* wr = wrows[rt];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) R.dd[i] = *(const uint32_t*)(crow[i] + (size_t)b * 4);
+            for (int j = 0; j < 4; ++j) R.q[j] = *(const u32x2*)(wr + (size_t)b * 128 + j * 32 + 8 * g);
+            if (KIND == WRK_MAT_Q5_K) R.qh = *(const u32x2*)(wr + (size_t)nb * 128 + (size_t)b * 32 + 8 * g);
+            R.sm = *(const u32x4*)(wr + soff + (size_t)b * 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) R.dd[i] = *(const uint32_t*)(crows[rt][i] + (size_t)b * 4);
+        };
+        auto load_w = [&](WBlk (&R)[NR], uint32_t b) {
+#pragma unroll
+            for (int rt = 0; rt < NR; ++rt) load_w1(R[rt], b, rt);
         };
         auto load_b = [&](BBlk& R, uint32_t b) {
 #pragma unroll
@@ -327,7 +348,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& P, float (*sh_tot)[N
                 for (int sb = 0; sb < 8; ++sb) R.bf[t][sb] = loadB(t, b * 256 + sb * 32);
         };
         // NT > 2 (prefill): B fragments are fetched per 64-k step instead (a whole block of them would be 128 VGPRs)
-        auto mul_blk = [&](const WBlk& R, const BBlk& X, uint32_t b, bool live) {
+        auto mul_blk1 = [&](const WBlk& R, const BBlk& X, uint32_t b, bool live, f32x4v (&total)[NT]) {
             f32x4v acc[NT], amin[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) { acc[t] = (f32x4v){0.f, 0.f, 0.f, 0.f}; amin[t] = (f32x4v){0.f, 0.f, 0.f, 0.f}; }
@@ -374,7 +395,11 @@ __device__ __forceinline__ void gemm_body(const GemmParams& P, float (*sh_tot)[N
         WRK_STAMP(P.dbg, 1);
         // weights TWO blocks ahead, B fragments one block ahead (16-token regime) or with the block (more tokens)
         // (four blocks ahead measured slower at 16 tokens: 18.3 vs 15.9 us for ffn.value -- register pressure, round 2)
-        WBlk W0, W1;
+        auto mul_blk = [&](const WBlk (&R)[NR], const BBlk& X, uint32_t b, bool live) {
+#pragma unroll
+            for (int rt = 0; rt < NR; ++rt) mul_blk1(R[rt], X, b, live, totals[rt]);
+        };
+        WBlk W0[NR], W1[NR];
         load_w(W0, blk(0));
         load_w(W1, blk(1));
         if (NT == 1) {
@@ -407,42 +432,51 @@ __device__ __forceinline__ void gemm_body(const GemmParams& P, float (*sh_tot)[N
     // combine the K slices
     if (wave > 0) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int rt = 0; rt < NR; ++rt)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) sh_tot[wave - 1][t][i][lane] = total[t][i];
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sh_tot[wave - 1][rt * NT + t][i][lane] = totals[rt][t][i];
     }
     __syncthreads();
     if (wave > 0) return;
     WRK_STAMP(P.dbg, 3);                // partial tiles met in LDS
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int rt = 0; rt < NR; ++rt)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float a = 0.0f;
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int w = 0; w < NW - 1; ++w) a += sh_tot[w][t][i][lane];
-            total[t][i] += a;
-        }
+            for (int i = 0; i < 4; ++i) {
+                float a = 0.0f;
+#pragma unroll
+                for (int w = 0; w < NW - 1; ++w) a += sh_tot[w][rt * NT + t][i][lane];
+                totals[rt][t][i] += a;
+            }
 
-    // store: lane owns rows m0 + 4g + (0..3) of token column r of each tile
+    // store: lane owns rows m0 + 16 rt + 4g + (0..3) of token column r of each tile
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const uint32_t tok = n0 + 16 * t + r;
-        if (tok >= P.n) continue;
-        float o[4];
+    for (int rt = 0; rt < NR; ++rt) {
+        const uint32_t mr = m0 + 16u * rt;
+        if (mr >= P.m) continue;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            o[i] = act_apply(P.act, total[t][i] * P.scale);
-            if (P.has_res) o[i] = (P.out32 ? o[i] : r16(o[i])) + (P.res32 ? __builtin_bit_cast(float, resb[t][i]) : (float)__builtin_bit_cast(f16, (uint16_t)resb[t][i]));
-        }
-        const size_t oo = (size_t)tok * P.os + m0 + 4 * g;
-        if (m0 + 4 * g + 4 <= P.m) {        // the common case: four consecutive rows in one store
-            if (P.out32) *(f32x4v*)((float*)P.out_p + oo) = (f32x4v){o[0], o[1], o[2], o[3]};
-            else { typedef _Float16 f16x4 __attribute__((ext_vector_type(4))); *(f16x4*)((f16*)P.out_p + oo) = (f16x4){(f16)o[0], (f16)o[1], (f16)o[2], (f16)o[3]}; }
-        } else {
+        for (int t = 0; t < NT; ++t) {
+            const uint32_t tok = n0 + 16 * t + r;
+            if (tok >= P.n) continue;
+            float o[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (m0 + 4 * g + i < P.m) { if (P.out32) ((float*)P.out_p)[oo + i] = o[i]; else ((f16*)P.out_p)[oo + i] = (f16)o[i]; }
+            for (int i = 0; i < 4; ++i) {
+                o[i] = act_apply(P.act, totals[rt][t][i] * P.scale);
+                if (P.has_res) o[i] = (P.out32 ? o[i] : r16(o[i])) + (P.res32 ? __builtin_bit_cast(float, resbs[rt][t][i]) : (float)__builtin_bit_cast(f16, (uint16_t)resbs[rt][t][i]));
+            }
+            const size_t oo = (size_t)tok * P.os + mr + 4 * g;
+            if (mr + 4 * g + 4 <= P.m) {        // the common case: four consecutive rows in one store
+                if (P.out32) *(f32x4v*)((float*)P.out_p + oo) = (f32x4v){o[0], o[1], o[2], o[3]};
+                else { typedef _Float16 f16x4 __attribute__((ext_vector_type(4))); *(f16x4*)((f16*)P.out_p + oo) = (f16x4){(f16)o[0], (f16)o[1], (f16)o[2], (f16)o[3]}; }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (mr + 4 * g + i < P.m) { if (P.out32) ((float*)P.out_p)[oo + i] = o[i]; else ((f16*)P.out_p)[oo + i] = (f16)o[i]; }
+            }
         }
     }
     WRK_STAMP(P.dbg, 4);
@@ -465,6 +499,22 @@ __global__ void __launch_bounds__(64 * NW) gemm_kernel(const GemmBatch B) {
         case WRK_MAT_INT8: gemm_body<WRK_MAT_INT8, NT, NW>(P, sh_tot); break;
         case WRK_MAT_NF4: gemm_body<WRK_MAT_NF4, NT, NW>(P, sh_tot); break;
         default: gemm_body<WRK_MAT_F16, NT, NW>(P, sh_tot); break;
+    }
+}
+
+// two row tiles per workgroup (<= 16 tokens, K4 kinds + F16 LoRA rows): see gemm_body
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) gemm_pair_kernel(const GemmBatch B) {
+    __shared__ float sh_tot[NW][2][4][64];
+    int ji = 0;
+#pragma unroll
+    for (int q = 1; q < GEMM_MAX_JOBS; ++q)
+        if (q < B.njobs && blockIdx.x >= B.jobs[q].wg_begin) ji = q;
+    const GemmParams& P = B.jobs[ji];
+    switch (P.kind) {
+        case WRK_MAT_Q4_K: gemm_body<WRK_MAT_Q4_K, 1, NW, 2>(P, sh_tot); break;
+        case WRK_MAT_Q5_K: gemm_body<WRK_MAT_Q5_K, 1, NW, 2>(P, sh_tot); break;
+        default: gemm_body<WRK_MAT_F16, 1, NW, 2>(P, sh_tot); break;
     }
 }
 
@@ -1749,7 +1799,22 @@ int matmul_mfma_multi(hipStream_t s, const MatJob* jobs, int njobs, int) {
         // threads spill the all-kinds kernel to scratch)
         if (n > 64) gemm_kernel<4, 4><<<dim3(wg, (n + 63) / 64), 256, 0, s>>>(B);
         else if (n > 16) { if (deep) gemm_kernel<2, 8><<<dim3(wg, (n + 31) / 32), 512, 0, s>>>(B); else gemm_kernel<2, 4><<<dim3(wg, (n + 31) / 32), 256, 0, s>>>(B); }
-        else { if (deep) gemm_kernel<1, 8><<<dim3(wg, (n + 15) / 16), 512, 0, s>>>(B); else gemm_kernel<1, 4><<<dim3(wg, (n + 15) / 16), 256, 0, s>>>(B); }
+        else {
+            // two row tiles per workgroup where that still leaves >= ~200 workgroups (r, k, v + LoRA, ffn key at 16 tokens).  MEASURED SLOWER
+            // (round 3, 1.5B decode, ms per step, pairs | single tiles: 8 sequences 1.339 | 1.244, 16 sequences 1.456 | 1.377): halving the
+            // activation re-reads does not pay for twice the serial blocks per wave -- these launches are bound by the dependent chain of a
+            // workgroup, not by the L2 bandwidth of the shared stack.  Off unless WRK_GEMM_PAIR=1 (kept for the A/B and its test).
+            const char* pe = getenv("WRK_GEMM_PAIR");
+            bool pair = pe && pe[0] == '1' && !deep && wg >= 400;
+            for (int q = 0; q < B.njobs; ++q) pair = pair && (B.jobs[q].kind == WRK_MAT_Q4_K || B.jobs[q].kind == WRK_MAT_Q5_K || B.jobs[q].kind == WRK_MAT_F16);
+            if (pair) {
+                uint32_t wg2 = 0;
+                for (int q = 0; q < B.njobs; ++q) { B.jobs[q].wg_begin = wg2; wg2 += (B.jobs[q].m + 31) / 32; }
+                gemm_pair_kernel<4><<<dim3(wg2, (n + 15) / 16), 256, 0, s>>>(B);
+            }
+            else if (deep) gemm_kernel<1, 8><<<dim3(wg, (n + 15) / 16), 512, 0, s>>>(B);
+            else gemm_kernel<1, 4><<<dim3(wg, (n + 15) / 16), 256, 0, s>>>(B);
+        }
     }
     return 0;
 }
