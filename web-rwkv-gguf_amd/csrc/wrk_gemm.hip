@@ -1804,6 +1804,8 @@ int matmul_mfma_multi(hipStream_t s, const MatJob* jobs, int njobs, int) {
             // (round 3, 1.5B decode, ms per step, pairs | single tiles: 8 sequences 1.339 | 1.244, 16 sequences 1.456 | 1.377): halving the
             // activation re-reads does not pay for twice the serial blocks per wave -- these launches are bound by the dependent chain of a
             // workgroup, not by the L2 bandwidth of the shared stack.  Off unless WRK_GEMM_PAIR=1 (kept for the A/B and its test).
+            const char* n8 = getenv("WRK_GEMM_NW8");           // A/B: eight waves split K for every launch of <= 16 tokens
+            const bool nw8 = n8 && n8[0] == '1';
             const char* pe = getenv("WRK_GEMM_PAIR");
             bool pair = pe && pe[0] == '1' && !deep && wg >= 400;
             for (int q = 0; q < B.njobs; ++q) pair = pair && (B.jobs[q].kind == WRK_MAT_Q4_K || B.jobs[q].kind == WRK_MAT_Q5_K || B.jobs[q].kind == WRK_MAT_F16);
@@ -1812,7 +1814,7 @@ int matmul_mfma_multi(hipStream_t s, const MatJob* jobs, int njobs, int) {
                 for (int q = 0; q < B.njobs; ++q) { B.jobs[q].wg_begin = wg2; wg2 += (B.jobs[q].m + 31) / 32; }
                 gemm_pair_kernel<4><<<dim3(wg2, (n + 15) / 16), 256, 0, s>>>(B);
             }
-            else if (deep) gemm_kernel<1, 8><<<dim3(wg, (n + 15) / 16), 512, 0, s>>>(B);
+            else if (deep || nw8) gemm_kernel<1, 8><<<dim3(wg, (n + 15) / 16), 512, 0, s>>>(B);
             else gemm_kernel<1, 4><<<dim3(wg, (n + 15) / 16), 256, 0, s>>>(B);
         }
     }

@@ -32,18 +32,51 @@ __global__ void __launch_bounds__(BLOCK) layer_norm_kernel(const f16* __restrict
     }
 }
 
-void layer_norm(hipStream_t s, const void* w, const void* b, DTensor x, float eps) {
-    dim3 grid(x.shape[1], x.shape[2]);
-    if (grid.x == 0 || grid.y == 0) return;
-    layer_norm_kernel<256><<<grid, 256, 0, s>>>((const f16*)w, (const f16*)b, x, x, eps, 0);
+// The same arithmetic for f16 rows of up to 256 NV channels (round 3): thread i still owns channels i, i + 256, ... and adds them in that order --
+// the sums are bit-identical to the kernel above -- but every operand is requested ONCE, up front and unconditionally, and kept in registers
+// for the three passes (the generic kernel re-loads the row per pass through dt_load, whose branch on the element type makes each load a
+// memory round trip of its own: 8.8 us per 128-token launch in pp512, a quarter of it after this).
+template <int NV>
+__global__ void __launch_bounds__(256) layer_norm_f16_kernel(const f16* __restrict__ w, const f16* __restrict__ b, DTensor src, DTensor x, float eps) {
+    __shared__ float red[4];
+    const uint32_t C = x.shape[0];
+    const uint32_t token = blockIdx.x, batch = blockIdx.y, tid = threadIdx.x;
+    const f16* sp = (const f16*)src.p + dt_index(src, 0, token, batch);
+    f16* xp = (f16*)x.p + dt_index(x, 0, token, batch);
+    f16 v[NV], wv[NV], bv[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) { const uint32_t i = min(tid + 256u * k, C - 1); v[k] = sp[i]; wv[k] = w[i]; bv[k] = b[i]; }
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) if (tid + 256u * k < C) s += (float)v[k];
+    const float mean = block_sum<4>(s, red) / (float)C;
+    float q = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) if (tid + 256u * k < C) { const float d = (float)v[k] - mean; q += d * d; }
+    const float var = block_sum<4>(q, red) / (float)C + eps;
+    const float dev = 1.0f / sqrtf(var);
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+        if (tid + 256u * k < C) xp[tid + 256u * k] = (f16)__builtin_fmaf(((float)v[k] - mean) * dev, (float)wv[k], (float)bv[k]);
 }
-
-// blit(src, x) + layer_norm(x) in one pass (the copy is exact, so the result is the same)
-void layer_norm_from(hipStream_t s, const void* w, const void* b, DTensor src, DTensor x, float eps) {
+static bool ln_dense_f16(const DTensor& d) { return d.dtype == WRK_F16 && d.stride[0] == d.shape[0] && d.offset[0] == 0; }
+static void layer_norm_launch(hipStream_t s, const void* w, const void* b, DTensor src, DTensor x, float eps) {
     dim3 grid(x.shape[1], x.shape[2]);
     if (grid.x == 0 || grid.y == 0) return;
+    const uint32_t C = x.shape[0];
+    static const bool fast = [] { const char* e = getenv("WRK_LN_FAST"); return !(e && e[0] == '0'); }();
+    if (fast && ln_dense_f16(src) && ln_dense_f16(x) && src.shape[0] == C && C <= 4096) {
+        if (C <= 2048) layer_norm_f16_kernel<8><<<grid, 256, 0, s>>>((const f16*)w, (const f16*)b, src, x, eps);
+        else layer_norm_f16_kernel<16><<<grid, 256, 0, s>>>((const f16*)w, (const f16*)b, src, x, eps);
+        return;
+    }
     layer_norm_kernel<256><<<grid, 256, 0, s>>>((const f16*)w, (const f16*)b, src, x, eps, 0);
 }
+
+void layer_norm(hipStream_t s, const void* w, const void* b, DTensor x, float eps) { layer_norm_launch(s, w, b, x, x, eps); }
+
+// blit(src, x) + layer_norm(x) in one pass (the copy is exact, so the result is the same)
+void layer_norm_from(hipStream_t s, const void* w, const void* b, DTensor src, DTensor x, float eps) { layer_norm_launch(s, w, b, src, x, eps); }
 
 void group_norm(hipStream_t s, const void* w, const void* b, DTensor x, float eps) {
     // x [S, H, T]: "token" = head, "batch" = token (ops.rs:460-508)
