@@ -55,7 +55,8 @@ struct EngArgs {
     const void* vecs;               // f16 [num_layer][ENG_NV][D]
     const float* scal;              // [num_layer][ENG_NS]
     unsigned long long* gran;       // granule buffer, zeroed before every launch
-    const void* x_in;               // f16 [D]: input of layer_begin (embedding LN output)
+    const void* x_in;               // f16 [D]: input of layer_begin (embedding LN output); with x_row: base of a table of such rows
+    const uint32_t* x_row;          // optional: row of x_in to take (the token id: the table is LN(ln0) of every embedding row, made at build time)
     void* x_out;                    // f16 [D]: output of layer_end - 1
     void* v_first;                  // f16 [D]: att_v0 (written by layer 0, read when the launch starts above it)
     float* state;                   // state base; layer l of sequence b at state + (l * num_batch + b) * state_rows * D
@@ -75,7 +76,10 @@ struct wrk_v7_engine;
 int32_t wrk_v7_engine_create(wrk_v7_model* m, wrk_v7_engine** out);    // WRK_E_UNSUPPORTED: the model / device does not fit the engine
 void wrk_v7_engine_destroy(wrk_v7_engine* e);
 // layers [l0, l1) of one decode token of sequence `batch`: x_in -> x_out (both f16 [D], may alias)
+// token: device pointer to the token id, or nullptr.  With a token (and layer 0 first) the engine reads its input from its table of
+// normalised embedding rows -- the embedding launch of the step is not needed -- and x_in is ignored.
 int32_t wrk_v7_engine_enqueue(wrk_v7_engine* e, hipStream_t q, wrk_v7_state* st, uint32_t batch, uint32_t l0, uint32_t l1, const void* x_in,
-                              void* x_out, void* v_first);
+                              void* x_out, void* v_first, const uint32_t* token = nullptr);
+bool wrk_v7_engine_has_table(const wrk_v7_engine* e);
 int32_t wrk_v7_engine_check(wrk_v7_engine* e);       // after a synchronisation: WRK_E_HIP if a launch gave up
 void wrk_v7_engine_report(wrk_v7_engine* e);         // WRK_TIMING=1: print the in-kernel timeline of the stamped layer

@@ -456,7 +456,7 @@ __global__ void __launch_bounds__((NCW + 2) * 64) v7_engine_kernel(const EngArgs
         for (uint32_t l = S.layer_begin; l < S.layer_end; ++l) {
             bool ok = true;
             // K1: the layer input
-            if (l == S.layer_begin) eng_copy_in(A.x_in, D >> 3, (ENG_LDS u32x4*)xraw0, lane);
+            if (l == S.layer_begin) eng_copy_in(A.x_row ? (const void*)((const f16*)A.x_in + (size_t)A.x_row[0] * D) : A.x_in, D >> 3, (ENG_LDS u32x4*)xraw0, lane);
             else ok = eng_gather(A.gran + S.g_x, D >> 2, eng_tag(l - 1, 4), (ENG_LDS uint32_t*)xraw0, lane);
             if (!ok && lane == 0) { *abort_flag = 1; atomicOr(A.fail, 1u); }
             ENG_STAMP(l, 0);
@@ -854,6 +854,7 @@ struct wrk_v7_engine {
     unsigned long long* gran = nullptr;     // device
     uint32_t* fail = nullptr;               // device (pinned readable through memcpy)
     unsigned long long* stamps = nullptr;   // device, WRK_TIMING=1
+    void* emb_ln = nullptr;                 // device f16 [V][D]: LN(ln0) of every embedding row (the same kernel as the step's embedding launch)
     bool r16 = false;
     int xd = 1, ncw = 8;
     uint32_t quant = 0;
@@ -1062,12 +1063,31 @@ int32_t wrk_v7_engine_create(wrk_v7_model* m, wrk_v7_engine** out) {
         }
         (void)hipGetLastError();
     }
+    // LN(ln0) of the whole embedding table, once (round 3): a decode step then starts with the engine itself -- its gather wave takes row
+    // `token` of this table -- instead of a gather + LN launch in front of it (4.9 us + a launch boundary per token).  V x D x 2 bytes of HBM.
+    // WRK_ENGINE_TABLE=0: off.
+    {
+        const char* te = getenv("WRK_ENGINE_TABLE");
+        if (!(te && te[0] == '0') && m->emb && m->ln0_w && m->ln0_b) {
+            const size_t bytes = (size_t)d.num_vocab * D * 2;
+            if (hipMalloc(&e->emb_ln, bytes) == hipSuccess) {
+                LnMixParams P{};
+                P.src = (const f16*)m->emb->ptr; P.ln_w = (const f16*)m->ln0_w->ptr; P.ln_b = (const f16*)m->ln0_b->ptr; P.eps = 1.0e-5f;
+                P.d = D; P.nmix = 0; P.ln_out = (f16*)e->emb_ln;
+                if (ln_mix(ctx->stream, P, d.num_vocab) != 0 || hipStreamSynchronize(ctx->stream) != hipSuccess) { hipFree(e->emb_ln); e->emb_ln = nullptr; }
+            } else e->emb_ln = nullptr;
+            (void)hipGetLastError();
+        }
+    }
     *out = e;
     return WRK_OK;
 }
 
+bool wrk_v7_engine_has_table(const wrk_v7_engine* e) { return e && e->emb_ln; }
+
 void wrk_v7_engine_destroy(wrk_v7_engine* e) {
     if (!e) return;
+    if (e->emb_ln) hipFree(e->emb_ln);
     if (e->layers) hipFree(e->layers);
     if (e->vecs) hipFree(e->vecs);
     if (e->scal) hipFree(e->scal);
@@ -1079,13 +1099,14 @@ void wrk_v7_engine_destroy(wrk_v7_engine* e) {
 }
 
 int32_t wrk_v7_engine_enqueue(wrk_v7_engine* e, hipStream_t q, wrk_v7_state* st, uint32_t batch, uint32_t l0, uint32_t l1, const void* x_in, void* x_out,
-                              void* v_first) {
+                              void* v_first, const uint32_t* token) {
     using namespace wrk;
     wrk_ctx* ctx = e->m->ctx;
     EngArgs A{};
     A.S = e->S;
     A.S.layer_begin = l0; A.S.layer_end = l1; A.S.batch = batch;
     A.layers = e->layers; A.vecs = e->vecs; A.scal = e->scal; A.gran = e->gran; A.x_in = x_in; A.x_out = x_out; A.v_first = v_first;
+    if (token && e->emb_ln && l0 == 0) { A.x_in = e->emb_ln; A.x_row = token; }
     A.state = st->data; A.num_batch = st->num_batch; A.fail = e->fail; A.stamps = e->stamps; A.stamp_layer = std::min(5u, l1 - 1);
     // every polled word zeroed before every launch (a memset node, replayed first): tags are > 0 and unique within a launch
     WRK_HIP(ctx, hipMemsetAsync(e->gran, 0, (size_t)e->S.g_total * 8, q));

@@ -559,8 +559,11 @@ int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_
     // the K-sliced GEMM's arrival counters must be zero when a step starts; its kernels leave them zero, but a launch that faulted or was
     // aborted would poison every later replay of this frame -- so the step program zeroes them first (a memset node, ~1 KB)
     if (T >= 2 && s.ks_cnt && s.ks_cnt_cap) WRK_HIP(ctx, hipMemsetAsync(s.ks_cnt, 0, (size_t)s.ks_cnt_cap * 4, q));
-    // embed: gather (device table) + LN(ln0) -> x   (v7.rs:438-474, 649-659)
-    if (!skip_embed) {
+    // embed: gather (device table) + LN(ln0) -> x   (v7.rs:438-474, 649-659).  One sequence's token on the engine: the engine takes the row from
+    // its table of normalised embedding rows itself (wrk_v7_engine.hip) -- no launch here
+    const bool eng_embeds = T == 1 && from_tokens && !skip_embed && layer_begin == 0 && engine_on() && !engine_skip_once && wrk_v7_engine_has_table(engine) &&
+                            d.num_layer > 0;
+    if (!skip_embed && !eng_embeds) {
         LnMixParams P{};
         if (from_tokens) { P.src = (const f16*)emb->ptr; P.ids = s.tokens; }
         else P.src = (const f16*)s.input;
@@ -573,7 +576,7 @@ int32_t wrk_v7_model::enqueue_fused_decode(wrk_v7_state* st, uint32_t T, uint32_
     if (T == 1 && engine_on() && !engine_skip_once) {
         const uint32_t l1 = std::min<uint32_t>(d.num_layer, layer_end);
         if (layer_begin < l1) {
-            const int32_t rc = wrk_v7_engine_enqueue(engine, q, st, cursor0_batch, layer_begin, l1, s.x, s.x, s.att_v0);
+            const int32_t rc = wrk_v7_engine_enqueue(engine, q, st, cursor0_batch, layer_begin, l1, s.x, s.x, s.att_v0, eng_embeds ? s.tokens : nullptr);
             if (rc != WRK_OK) return rc;
         }
         first_launch_layer = l1;
