@@ -222,7 +222,8 @@ int32_t wrk_v7_model::enqueue_ops(wrk_v7_state* st, uint32_t T, uint32_t NH, boo
                 MM(L.v2, aux_v, vv, WRK_ACT_NONE);
             }
         }
-        float* wdec = (size_t)F * (act_dtype == WRK_F32 ? 4 : 2) >= (size_t)4 * D ? (float*)s.ffn_k : nullptr;
+        // (not with many sequences: the one-wave-per-head kernel prepares its decays itself, and 4 D bytes per token would be written for nothing)
+        float* wdec = ((size_t)F * (act_dtype == WRK_F32 ? 4 : 2) >= (size_t)4 * D && (size_t)wkv_nseq * H < 768) ? (float*)s.ffn_k : nullptr;
         if (m_pre) {     // steps 5-11's element-wise ops in one launch, bit-identical (wrk_ops.hip: pre_wkv_v7)
             // (the decays of the chunk kernel ride along, f32 [D, T], in the ffn key buffer: 4 D values per token, free until the ffn key GEMM)
             wrk::pre_wkv_v7(q, s.w, s.a, s.k, s.v, s.vv, s.att_v0, s.n, L.w0->ptr, L.a0->ptr, L.k_k->ptr, L.k_a->ptr, li ? L.v0->ptr : L.a0->ptr,
