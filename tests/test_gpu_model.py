@@ -279,6 +279,31 @@ def test_concurrent_pipelines_equal_separate_runs(ctx, B, groups):
         assert toks[step].tolist() == cur, step
 
 
+def test_frame_dtype_switch_reaches_the_pipeline_lanes(ctx):
+    """lanes of a grouped generate_greedy used to keep the frame dtype they were created with.  After a switch to f32 frames (and
+    back) every block of a grouped call must still equal the same block decoded alone at the SAME frame dtype, bit for bit."""
+    data = synth.make_v7_gguf(synth.CONFIGS["tiny"], 11)
+    V = synth.CONFIGS["tiny"].num_vocab
+    B, groups = 4, 2
+    first = [(3 + 41 * b) % (V - 1) for b in range(B)]
+    rt = wrk.Runtime(ctx, wrk.GgufReader(data), num_batch=B)
+    rt.generate_greedy(first, 3, mode=1, groups=groups)                 # lanes now exist, with f16 frames
+    for dtype in (wrk.F32, wrk.F16):
+        rt.set_frame_dtype(dtype)
+        for b in range(B):
+            rt.state_load(np.zeros_like(rt.state_back(b)), b)
+        toks, _, logits = rt.generate_greedy(first, 6, mode=1, want_logits=True, groups=groups)
+        for g in range(groups):
+            b0, b1 = B * g // groups, B * (g + 1) // groups
+            alone = wrk.Runtime(ctx, wrk.GgufReader(data), num_batch=b1 - b0)
+            alone.set_frame_dtype(dtype)
+            t, _, l = alone.generate_greedy(first[b0:b1], 6, mode=1, want_logits=True)
+            assert np.array_equal(toks[:, b0:b1], t), (dtype, g)
+            assert np.array_equal(logits[b0:b1], l), (dtype, g)
+            alone.close()
+    rt.close()
+
+
 @pytest.mark.parametrize("B", [9, 20])
 def test_k_sliced_gemm_runs_are_bit_identical(ctx, B, monkeypatch):
     """Every GEMM of a 9 / 20-sequence decode on the K-sliced kernel (WRK_GEMM_KS=2): its K slices meet in-kernel through write-through

@@ -1505,7 +1505,10 @@ __device__ __forceinline__ void gemm_ks_body(const GemmParams& P, const KsJob& E
         // used release / acquire fences (buffer_wbl2 + buffer_inv per workgroup) and ran 4x SLOWER than the kernels it replaces -- every
         // workgroup wrote back and invalidated its XCD's whole L2, activations included.  Order: this wave's tile stores are performed
         // (vmcnt(0)) before the workgroup barrier, the counter is bumped after it; the last arriver's loads are issued after it has seen
-        // the count.
+        // the count.  ISA assumptions (gfx942 / gfx950): `sc1` on a global store = write-through to agent (device) scope, `sc1` on a load =
+        // served at agent scope (not from this XCD's L2 copy); `s_waitcnt vmcnt(0)` returns only when the wave's stores have been acknowledged
+        // at that scope (loads and stores share the counter and return in order).  Nothing here orders OTHER addresses: only the tiles and the
+        // counter are exchanged.  WRK_GEMM_KS=0 switches the kernel off; the step program zeroes the counters before every step.
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             float* pp = p0 + (size_t)z * tile + (size_t)(16 * t + r) * 64 + wave * 16 + 4 * g;
