@@ -50,7 +50,7 @@ def ulps(got, want):
 STATS = {}
 
 
-def check(case, name, got, want, direct):
+def check(case, name, got, want, direct, downstream_max_ulp=None):
     u = ulps(got.reshape(want.shape), want)
     s = STATS.setdefault(case, {}).setdefault(name, {"max_ulp": 0.0, "min_frac_le1": 1.0, "min_frac_exact": 1.0, "n": 0, "max_strict_ulp": 0.0,
                                                      "min_frac_strict_le1": 1.0})
@@ -63,7 +63,7 @@ def check(case, name, got, want, direct):
     s["min_frac_le1"] = min(s["min_frac_le1"], float((u <= 1.0).mean()))
     s["min_frac_exact"] = min(s["min_frac_exact"], float((u == 0).mean()))
     s["n"] += 1
-    max_ulp, frac1 = (DIRECT_MAX_ULP, 1.0) if direct else (DOWNSTREAM_MAX_ULP, DOWNSTREAM_FRAC_LE1)
+    max_ulp, frac1 = (DIRECT_MAX_ULP, 1.0) if direct else (downstream_max_ulp or DOWNSTREAM_MAX_ULP, DOWNSTREAM_FRAC_LE1)
     assert u.max() <= max_ulp, f"{case} {name}: {u.max():.2f} ulp (limit {max_ulp}); {int((u > 1).sum())} of {u.size} elements beyond 1 ulp"
     assert (u <= 1.0).mean() >= frac1, f"{case} {name}: only {(u <= 1.0).mean():.5f} of the elements within 1 ulp"
 
@@ -87,7 +87,7 @@ MODE1 = [("att_x_ln", "att_x_ln", True), ("att_r", "r", True), ("att_k", "k_raw"
 MERGED = [("att_r", "r", True), ("att_x", "att_x", False), ("ffn_k", "ffn_k", False), ("x", "x", False)]
 
 
-def run_case(ctx, name, weights, kw, mode, chunk_lens, steps):
+def run_case(ctx, name, weights, kw, mode, chunk_lens, steps, downstream_max_ulp=None):
     data = synth.make_v7_gguf(synth.CONFIGS[name], 42, **kw)
     rt = wrk.Runtime(ctx, wrk.GgufReader(data), num_batch=len(chunk_lens), weights=weights)
     model = O.build_v7(ogguf.GgufReader(data), weights_f16=(weights != wrk.WEIGHTS_INLINE))
@@ -125,7 +125,7 @@ def run_case(ctx, name, weights, kw, mode, chunk_lens, steps):
                 if buf.endswith("x") and buf.startswith("att_") and len(buf) == 6 and T > 1:
                     direct = False          # att_rx .. att_gx of a chunk mix two LN rows (the previous token's and this one's)
                 got = rt.frame(buf, T).astype(np.float32)
-                check(case, buf, got, tr[f"{li}_{key}"], direct)
+                check(case, buf, got, tr[f"{li}_{key}"], direct, downstream_max_ulp)
             for b in range(len(chunk_lens)):
                 got, want = rt.state_back(b)[li], oracle.state.back(b)[li]
                 d = np.abs(got - want)
@@ -181,6 +181,17 @@ def test_decode_layer_by_layer_headline_layer_shape(ctx, mode):
     this case shows, buffer by buffer on the 2048-wide layer, whether a kernel of mode 1 is further from the oracle than its mode-0
     counterpart or whether the difference is propagation (stats -> profiles/r03_layer_parity_1p5b.json)."""
     run_case(ctx, "1.5B-3L", wrk.WEIGHTS_INLINE_F16, {}, mode, [1], 3)
+
+
+@pytest.mark.parametrize("lens", [[128], [100, 100]])
+def test_prefill_chunks_on_the_k_split_tile_at_the_headline_layer_shape(ctx, lens):
+    """Round 3: chunks of 128 - 256 tokens at the 1.5B layer shape, mode 1.  128 tokens: the ffn value (K = 8192) on the K-split third-generation
+    tile (partial tiles + reduce launch), the other matrices on the first-generation tile; 200 tokens of two sequences: every Q4_K matrix on the
+    K-split tile; WKV chunk kernel with precomputed decays, eight threads per state column, a head's columns over several workgroups.
+    Downstream bar 8 ulp here: 409 600 elements per buffer behind up to 100 steps of the recurrence -- the post-WKV buffer has ONE element at 7 ulp
+    (99.6 % within 1 ulp), and has it with the K-split tile, the third-generation tile and the eight-thread kernel each switched off
+    (tools/lp_probe.sh): the tail of the distribution at this size, not a kernel."""
+    run_case(ctx, "1.5B-3L", wrk.WEIGHTS_INLINE, {}, 1, lens, 1, downstream_max_ulp=8.0)
 
 
 @pytest.mark.parametrize("mode", [0, 1])
