@@ -111,6 +111,7 @@ __device__ __forceinline__ void t3_dequant(const T3W& R, uint32_t b, uint32_t nb
 //                                                                            drain 156 | waiting at the barrier 1 330  = 4 380 cycles (the matrix pipe needs 1 024)
 //   + global loads behind the first MFMA group, C = 0 on a block's first step  127.0 k: 331 | 1 860 | 765 | 305 | 1 257: the time moved, the half did not get shorter
 //   + activations by LDS-DMA (no staging registers, no LDS stores for them)  124.9 k: 290 | 1 853 | 726 | 235 | 1 310 (225 registers instead of 253; not kept)
+//   + waves 4 - 7 produce first and multiply afterwards, waves 0 - 3 the other way round (SIMD partners out of phase)   120.7 k vs 121.8 k same box: nothing (not kept)
 // So a half costs ~4 400 cycles whatever is moved or removed: the two waves of a SIMD run the same phases at the same time (the barrier every
 // half re-aligns them), so one wave's vector work does not fill the other's matrix-pipe gaps, and wave 0 spends 30 % of a half waiting for
 // its SIMD partner.  What is left to try: block scales applied while the NEXT block multiplies (needs a second accumulator set: 257 registers
