@@ -168,6 +168,7 @@ def test_gemm_activation_residual_f16_out_and_vec_agreement(ctx):
     ("Q4_K", 2560, 260, 530), ("Q4_K", 8192, 132, 515), ("Q4_K", 1280, 128, 512),
     # the same tile from 128 tokens on, K split over workgroups (slices of 4 / 2 / 1 blocks, partial tiles added in slice order): slices that start
     # inside a group of four blocks, a last slice shorter than the others, one token tile and two, ragged rows
+    ("Q5_K", 2048, 260, 200), ("Q5_K", 4096, 132, 128), ("Q5_K", 3584, 130, 520),        # Q5_K on the same tile (round 3): the fifth bit from the qh plane
     ("Q4_K", 8192, 132, 140), ("Q4_K", 2048, 260, 128), ("Q4_K", 2560, 384, 256), ("Q4_K", 1024, 2052, 130), ("Q4_K", 1536, 128, 250), ("Q4_K", 2048, 6144, 128),
     ("Q8_0", 2048, 520, 600), ("Q8_0", 1024, 1028, 530), ("Q8_0", 4096, 1100, 520), ("Q8_0", 128, 2052, 640),         # Q8_0: that kernel only
     ("Q8_0", 2048, 520, 200), ("Q8_0", 1024, 1028, 130), ("Q8_0", 128, 2052, 100), ("Q8_0", 2560, 260, 70),           # round 3: Q8_0 chunks of 48 .. 511 tokens on the same kernel

@@ -431,7 +431,7 @@ int32_t wrk_op_matmul(wrk_ctx* ctx, const wrk_matrix* mat, const wrk_tensor* inp
     j.scale = mat->out_scale;
     int rc = -2;
     const size_t ntok = (size_t)input->view.shape[1] * input->view.shape[2];
-    if (turbo && ntok >= 128 && mat->kind == WRK_MAT_Q4_K) {                             // the third-generation prefill tile wants its sum scratch
+    if (turbo && ntok >= 128 && (mat->kind == WRK_MAT_Q4_K || mat->kind == WRK_MAT_Q5_K)) {                             // the third-generation prefill tile wants its sum scratch
         // (+ the f32 partial tiles of a K-split launch: chunks of up to 256 tokens, at most one slice per 256-block)
         const size_t part = ntok <= 256 ? ntok * (size_t)mat->m * (mat->k >> 8) * 4 : 0;
         const int32_t rs = wrk_ctx_reserve_gemm_scratch(ctx, ntok * (mat->k >> 5) * 4 + 1024 + part);

@@ -1747,7 +1747,7 @@ int matmul_mfma_multi(hipStream_t s, const MatJob* jobs, int njobs, int) {
         // the kernels below): 128 tokens 21.5 k | 21.6 k with every matrix on it -- only the long rows gain (ffn value, K = 8192: 49.5 us -> 16 + 6.5 + 5);
         // 256 tokens 38.9 k | 35.8 k; 384 tokens (three token tiles, no split) 37.8 k | 46.6 k
         const bool t3_n = n >= 512 || (n > 128 && n <= 256) || (n == 128 && j.k >= 4096);
-        if (use_tile3 && t3_n && j.kind == WRK_MAT_Q4_K && j.m >= 128 && j.in.shape[2] == 1 && (j.k & 255u) == 0 && T3.njobs < GEMM_MAX_JOBS) {
+        if (use_tile3 && t3_n && (j.kind == WRK_MAT_Q4_K || j.kind == WRK_MAT_Q5_K) && j.m >= 128 && j.in.shape[2] == 1 && (j.k & 255u) == 0 && T3.njobs < GEMM_MAX_JOBS) {
             fill_job(T3.jobs[T3.njobs++], j, n, t3wg);
             t3wg += (j.m + 127) / 128;
             continue;

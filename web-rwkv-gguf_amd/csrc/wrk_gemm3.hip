@@ -1,4 +1,4 @@
-// Third-generation prefill tile GEMM for gfx950 (round 3): Y[M, N] = act(W[M, K] . X[K, N]) for Q4_K matrices and >= 512 stacked tokens.
+// Third-generation prefill tile GEMM for gfx950 (round 3): Y[M, N] = act(W[M, K] . X[K, N]) for Q4_K / Q5_K matrices and >= 128 stacked tokens.
 //
 // Replaces matmul_mat_q4k(_opt) (ops.rs:1332-1536, shaders/matmul_mat_q4k_opt.wgsl:86-229: 32 x 32 tile, f32 FMA).  Semantics: gguf.rs:95-143.
 //
@@ -65,16 +65,23 @@ __global__ void __launch_bounds__(256) xsum_kernel(const f16* __restrict__ x, ui
     sl[idx] = (f16)(s - (float)h);
 }
 
-struct T3W { u32x2 q[4]; u32x4 sm; uint32_t dd; };
+struct T3W { u32x2 q[4]; u32x4 sm; uint32_t dd; u32x2 qh; };        // qh: Q5_K high bits of this lane's 8 columns (bit s = sub-block s)
 
 // Dequantise one 32-k piece (PC = 0 .. 3) of half HF (k = 128 HF .. +127) of a block of ONE 16-row tile (rows 16 * tile + r of the workgroup: a wave's own
 // tile) into the A image.  Pieces are issued BETWEEN the MFMA groups of the half that is being multiplied (round 3, second build: the unpacking
 // and the LDS stores of the next half run while the matrix pipe works through the current one instead of after it).
 template <int HF, int PC>
-__device__ __forceinline__ void t3_dequant_piece(const T3W& R, f16* __restrict__ dst) {     // dst: As + t3_off(16 tile + r, 4 PC + g)
+__device__ __forceinline__ void t3_dequant_piece(const T3W& R, f16* __restrict__ dst, bool q5) {     // dst: As + t3_off(16 tile + r, 4 PC + g); q5: uniform
     constexpr int j = 2 * HF + (PC >> 1);
     const u32x2 q = R.q[j];
     const uint32_t v = R.sm[j];
+    if (q5) {       // Q5_K (round 3, as gemm_body): the fifth bit of sub-block s = 2 j + (PC & 1) is bit s of the lane's qh bytes; q <= 31, q * sc <= 1953: exact
+        constexpr uint32_t sb = 2 * j + (PC & 1);
+        const uint32_t lo0 = (PC & 1) ? ((q.x >> 4) & 0x0f0f0f0fu) : (q.x & 0x0f0f0f0fu), lo1 = (PC & 1) ? ((q.y >> 4) & 0x0f0f0f0fu) : (q.y & 0x0f0f0f0fu);
+        const uint32_t c0 = lo0 | (((R.qh.x >> sb) & 0x01010101u) << 4), c1 = lo1 | (((R.qh.y >> sb) & 0x01010101u) << 4);
+        *(f16x8*)dst = mul8(codes8(c0, c1), (float)((PC & 1) ? ((v >> 8) & 0xffu) : (v & 0xffu)) * 1024.0f);
+        return;
+    }
     if ((PC & 1) == 0) *(f16x8*)dst = mul8(codes8(q.x & 0x0f0f0f0fu, q.y & 0x0f0f0f0fu), (float)(v & 0xffu) * 1024.0f);            // q * sc * 2^-14, exact
     else *(f16x8*)dst = mul8(codes8(q.x & 0xf0f0f0f0u, q.y & 0xf0f0f0f0u), (float)((v >> 8) & 0xffu) * 64.0f);
 }
@@ -99,9 +106,9 @@ __device__ __forceinline__ void t3_dequant_meta(const T3W& R, uint32_t b, uint32
 }
 template <int HF>
 __device__ __forceinline__ void t3_dequant(const T3W& R, uint32_t b, uint32_t nb, f16* __restrict__ As, float* __restrict__ Dd, f16* __restrict__ Amh,
-                                           f16* __restrict__ Aml, uint32_t tile, uint32_t r, uint32_t g) {
-    t3_dequant_piece<HF, 0>(R, As + t3_off(16u * tile + r, 0u + g)); t3_dequant_piece<HF, 1>(R, As + t3_off(16u * tile + r, 4u + g));
-    t3_dequant_piece<HF, 2>(R, As + t3_off(16u * tile + r, 8u + g)); t3_dequant_piece<HF, 3>(R, As + t3_off(16u * tile + r, 12u + g));
+                                           f16* __restrict__ Aml, uint32_t tile, uint32_t r, uint32_t g, bool q5) {
+    t3_dequant_piece<HF, 0>(R, As + t3_off(16u * tile + r, 0u + g), q5); t3_dequant_piece<HF, 1>(R, As + t3_off(16u * tile + r, 4u + g), q5);
+    t3_dequant_piece<HF, 2>(R, As + t3_off(16u * tile + r, 8u + g), q5); t3_dequant_piece<HF, 3>(R, As + t3_off(16u * tile + r, 12u + g), q5);
     if (HF == 0) t3_dequant_meta(R, b, nb, Dd, Amh, Aml, tile, r, g);
 }
 
@@ -145,12 +152,14 @@ __global__ void __launch_bounds__(512) gemm_tile3_kernel(const T3Batch B) {
     const uint32_t b_begin = B.kslices > 1 ? blockIdx.z * B.bps : 0u, b_end = B.kslices > 1 ? min(nb, b_begin + B.bps) : nb;
     // dequant role: rows m0 + 16 wave + r
     const uint8_t* wrow = P.w + (size_t)min(m0 + 16u * wave + r, P.m - 1) * P.row_bytes;
-    const uint32_t hoff = nb * 128, soff = hoff + nb * 4;
+    const bool q5 = P.kind == WRK_MAT_Q5_K;                 // uniform over the workgroup
+    const uint32_t hoff = q5 ? nb * 160 : nb * 128, soff = hoff + nb * 4;
     auto load_w = [&](T3W& R, uint32_t b0) {
         const uint32_t b = min(b0, nb - 1);
-        if (DIAG == 2) { for (int j = 0; j < 4; ++j) R.q[j] = (u32x2){b0, b0}; R.sm = (u32x4){1, 1, 1, 1}; R.dd = 1; return; }
+        if (DIAG == 2) { for (int j = 0; j < 4; ++j) R.q[j] = (u32x2){b0, b0}; R.sm = (u32x4){1, 1, 1, 1}; R.dd = 1; R.qh = (u32x2){0, 0}; return; }
 #pragma unroll
         for (int j = 0; j < 4; ++j) R.q[j] = *(const u32x2*)(wrow + (size_t)b * 128 + j * 32 + 8 * g);
+        R.qh = *(const u32x2*)(q5 ? wrow + (size_t)nb * 128 + (size_t)b * 32 + 8 * g : wrow);      // unconditional (Q4_K: a dummy inside the row)
         R.sm = *(const u32x4*)(wrow + soff + (size_t)b * 16);
         R.dd = *(const uint32_t*)(wrow + hoff + (size_t)b * 4);
     };
@@ -210,7 +219,7 @@ __global__ void __launch_bounds__(512) gemm_tile3_kernel(const T3Batch B) {
         const uint32_t rowo = (16u * wave + r) * T3_MR;
         for (uint32_t bb = 0; bb < (b_begin & 3u); ++bb) { *(f16x2*)(Amh + rowo + bb * 8u + 2u * g) = z; *(f16x2*)(Aml + rowo + bb * 8u + 2u * g) = z; }
     }
-    t3_dequant<0>(W0, b_begin, b_end, As, Dd, Amh, Aml, wave, r, g);
+    t3_dequant<0>(W0, b_begin, b_end, As, Dd, Amh, Aml, wave, r, g, q5);
     store_x(stage0, 0);
     __syncthreads();
 
@@ -242,8 +251,8 @@ __global__ void __launch_bounds__(512) gemm_tile3_kernel(const T3Batch B) {
         const bool more = hf == 0 || b + 1 < b_end;
         auto produce = [&](auto pc) {
             constexpr int PC = decltype(pc)::value;
-            if (hf == 0) t3_dequant_piece<1, PC>(Rc, As + (size_t)128 * T3_LR + d_base + kof[PC]);
-            else if (more) t3_dequant_piece<0, PC>(Rn, As + d_base + kof[PC]);
+            if (hf == 0) t3_dequant_piece<1, PC>(Rc, As + (size_t)128 * T3_LR + d_base + kof[PC], q5);
+            else if (more) t3_dequant_piece<0, PC>(Rn, As + d_base + kof[PC], q5);
             if (hf == 0) store_x1(stage1, 1u, PC); else store_x1(stage0, 0u, PC);
         };
         frags(0, 0);

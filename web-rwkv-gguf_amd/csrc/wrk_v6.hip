@@ -71,6 +71,13 @@ int32_t wrk_v6_model::ensure_scratch(uint32_t T, uint32_t NH) {
     }
     WRK_HIP(ctx, hipMalloc(&scratch, off));
     WRK_HIP(ctx, hipMemsetAsync(scratch, 0, off, ctx->stream));
+    if (nt >= 128) {
+        // prefill GEMM (wrk_gemm3.hip, Q4_K / Q5_K): sub-block input sums of the stacked tokens for the up to four distinct inputs of a launch (the
+        // k, v, r, g projections read four shifted inputs) or the F-wide ffn vector, + the f32 partial tiles of K-split launches (chunks <= 256 tokens)
+        const size_t widest = std::max<size_t>(4 * D, F);
+        const int32_t rs = wrk_ctx_reserve_gemm_scratch(ctx, (size_t)nt * (widest / 32) * 4 + 16 * 1024 + (size_t)256 * widest * 4 * 4);
+        if (rs != WRK_OK) return rs;
+    }
     char* b = (char*)scratch;
     s.ks_part = ks_floats ? (float*)(b + o_ksp) : nullptr; s.ks_cnt = ks_floats ? (uint32_t*)(b + o_ksc) : nullptr;
     s.ks_part_cap = ks_floats; s.ks_cnt_cap = (uint32_t)ks_groups;
@@ -99,6 +106,7 @@ int32_t wrk_v6_model::ensure_history(size_t n) {
 static int32_t mm6(wrk_ctx* ctx, const wrk_matrix* m, DTensor in, DTensor out, uint32_t act) {
     wrk::MatJob j{m->data, m->aux, m->kind, m->flags, m->k, m->m, (uint32_t)m->row_bytes, in, out, act, 0};
     j.scale = m->out_scale;
+    j.xsum = ctx->gemm_scratch; j.xsum_cap = ctx->gemm_scratch_cap;        // third-generation prefill tile (Q4_K / Q5_K chunks)
     int rc = -2;
     if (in.shape[1] * in.shape[2] >= wrk::gemm_min_tokens()) rc = wrk::matmul_mfma(ctx->op_stream(), j, ctx->num_cu);
     if (rc == -2) rc = wrk::matvec(ctx->op_stream(), &j, 1, ctx->num_cu);
@@ -114,6 +122,7 @@ static wrk::MatJob job6m(const wrk_matrix* m, DTensor in, DTensor out, uint32_t 
 // several matrices x the same token count in one MFMA launch per kernel family; per-matrix launches when the GEMM declines
 static int32_t mm6_group(wrk_ctx* ctx, wrk::MatJob* jobs, int n) {
     const uint32_t T = jobs[0].in.shape[1] * jobs[0].in.shape[2];
+    for (int i = 0; i < n; ++i) { jobs[i].xsum = ctx->gemm_scratch; jobs[i].xsum_cap = ctx->gemm_scratch_cap; }
     if (T >= wrk::gemm_min_tokens() && wrk::matmul_mfma_multi(ctx->op_stream(), jobs, n, ctx->num_cu) == 0) return WRK_OK;
     for (int i = 0; i < n; ++i) {
         int rc = -2;
