@@ -1018,6 +1018,84 @@ __global__ void __launch_bounds__(256) time_mix_v6_fast_kernel(const uint32_t* _
     for (int jj = 0; jj < 16; ++jj) sbase[dt_index(st, ch, 1 + part * 16 + jj, cur.batch)] = Sreg[jj];
 }
 
+// One wave per (head, sequence), as time_mix_v7_wave_kernel (round 3): lane i owns the state column S[0..63][i]; the per-row operands (decay w, k, r: f32 here)
+// are loaded lane-parallel -- lane j takes channel j of the next tokens -- and read back from a double-buffered LDS row at uniform addresses; the bonus u is
+// constant per head (64 registers).  The sum over j runs as four chains of sixteen in the quad kernel's order, (P0 + P1) + (P2 + P3): bit-identical to it.
+// 16 sequences x 64 heads of the 7B model: one wave per SIMD of the chip instead of two rounds of 4-wave workgroups.
+__global__ void __launch_bounds__(64) time_mix_v6_wave_kernel(const uint32_t* __restrict__ cursors, DTensor decay, const float* __restrict__ u, DTensor st, DTensor k,
+                                                               DTensor v, DTensor r, DTensor x, uint32_t ntok) {
+    constexpr int S = 64;
+    struct Slot { float w[S], k[S], r[S]; };
+    __shared__ __attribute__((aligned(16))) Slot sh[2];
+    const uint32_t head = blockIdx.x;
+    Cursor cur;
+    if (!find_sequence(cursors, ntok, blockIdx.y, cur)) return;
+    const uint32_t lane = threadIdx.x, ch = head * S + lane;
+    const uint32_t tend = cur.token + cur.len;
+    dt_store(st, dt_index(st, ch, 0, cur.batch), dt_load(x, dt_index(x, lane, head, tend - 1)));       // token-shift carry (read before x is overwritten)
+    float Sreg[S], uu[S];
+    float* sbase = (float*)st.p;
+#pragma unroll
+    for (int j = 0; j < S; ++j) { Sreg[j] = sbase[dt_index(st, ch, 1 + j, cur.batch)]; uu[j] = u[head * S + j]; }
+    struct Tok { float w, k, r, v; };
+    const size_t rstep = (size_t)r.stride[1] * r.stride[0], kstep = (size_t)k.stride[1] * k.stride[0];
+    const size_t wstep = (size_t)decay.stride[1] * decay.stride[0], vstep = (size_t)v.stride[1] * v.stride[0], xstep = (size_t)x.stride[1] * x.stride[0];
+    const float* rp = (const float*)r.p + dt_index(r, lane, head, cur.token);
+    const float* kp = (const float*)k.p + dt_index(k, lane, head, cur.token);
+    const float* wp = (const float*)decay.p + dt_index(decay, lane, head, cur.token);
+    const float* vp = (const float*)v.p + dt_index(v, lane, head, cur.token);
+    f16* xp = (f16*)x.p + dt_index(x, lane, head, cur.token);
+    uint32_t lpos = cur.token;
+    auto load_tok = [&](Tok& T, bool adv) {       // unconditional loads: the pointers stop at the last token
+        rp += adv ? rstep : 0; kp += adv ? kstep : 0; wp += adv ? wstep : 0; vp += adv ? vstep : 0;
+        lpos += adv ? 1u : 0u;
+        T.w = *wp; T.k = *kp; T.r = *rp; T.v = *vp;
+    };
+    auto prepare = [&](const Tok& T, Slot& L) { L.w[lane] = T.w; L.k[lane] = T.k; L.r[lane] = T.r; };
+    constexpr int NPF = 4;
+    Tok T[NPF];
+    load_tok(T[0], false);
+#pragma unroll
+    for (int q = 1; q < NPF; ++q) load_tok(T[q], lpos + 1 < tend);
+    prepare(T[0], sh[cur.token & 1u]);
+    auto step = [&](uint32_t t, Tok& Tc, const Tok& Tn) {
+        const Slot& L = sh[t & 1u];
+        prepare(Tn, sh[(t + 1) & 1u]);
+        const float vv = Tc.v;
+        load_tok(Tc, lpos + 1 < tend);
+        float P[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            float y = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 w4 = *(const f32x4*)(L.w + 16 * p + 4 * q), k4 = *(const f32x4*)(L.k + 16 * p + 4 * q), r4 = *(const f32x4*)(L.r + 16 * p + 4 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int j = 16 * p + 4 * q + e;
+                    const float kv = k4[e] * vv;
+                    y += r4[e] * __builtin_fmaf(uu[j], kv, Sreg[j]);
+                    Sreg[j] = __builtin_fmaf(w4[e], Sreg[j], kv);
+                }
+            }
+            P[p] = y;
+        }
+        const float y = (P[0] + P[1]) + (P[2] + P[3]);
+        *xp = (f16)y;
+        xp += xstep;
+    };
+    uint32_t tb = cur.token;
+    for (; tb + NPF <= tend; tb += NPF) {
+#pragma unroll
+        for (int q = 0; q < NPF; ++q) step(tb + q, T[q], T[(q + 1) % NPF]);
+    }
+#pragma unroll
+    for (int q = 0; q < NPF - 1; ++q)
+        if (tb + q < tend) step(tb + q, T[q], T[(q + 1) % NPF]);
+#pragma unroll
+    for (int j = 0; j < S; ++j) sbase[dt_index(st, ch, 1 + j, cur.batch)] = Sreg[j];
+}
+
 static bool dense_f32_heads(const DTensor& d) {
     return d.dtype == WRK_F32 && d.shape[0] == 64 && d.stride[0] == 64 && d.offset[0] == 0 && (((uintptr_t)d.p) & 15u) == 0;
 }
@@ -1027,7 +1105,11 @@ void time_mix_v6(hipStream_t s, const uint32_t* cursors, DTensor decay, const vo
     dim3 grid(r.shape[1], r.shape[2]);
     if (dense_f32_heads(decay) && dense_f32_heads(k) && dense_f32_heads(v) && dense_f32_heads(r) && dense_f16_heads(x) && st.dtype == WRK_F32) {
         const uint32_t T = r.shape[2], slots = std::min(T, st.shape[2]);       // at most one sequence per batch of the state and per token
-        time_mix_v6_fast_kernel<<<dim3(r.shape[1], slots), 256, 0, s>>>(cursors, decay, (const float*)u, st, k, v, r, x, T);
+        // one wave per head once the sequence slots put a wave on three of four SIMDs (no hint here: as many sequences as the state has batches)
+        const char* fe = getenv("WRK_WKV_WAVE");
+        const bool wave = fe ? atoi(fe) != 0 : (size_t)slots * r.shape[1] >= 768;
+        if (wave) time_mix_v6_wave_kernel<<<dim3(r.shape[1], slots), 64, 0, s>>>(cursors, decay, (const float*)u, st, k, v, r, x, T);
+        else time_mix_v6_fast_kernel<<<dim3(r.shape[1], slots), 256, 0, s>>>(cursors, decay, (const float*)u, st, k, v, r, x, T);
         return;
     }
     time_mix_v6_kernel<<<grid, 256, 0, s>>>(cursors, decay, (const float*)u, st, k, v, r, x);
