@@ -154,7 +154,8 @@ void post_wkv_v7(hipStream_t s, void* x, const void* r, const void* g, const voi
 // n <= 6 token_shift ops over the same input / state row in one pass (falls back to n launches for views it cannot vectorise)
 void token_shift_multi(hipStream_t s, const uint32_t* cursors, const DTensor* mix, const DTensor* out, int n, DTensor state, DTensor in, int reversed);
 void transpose(hipStream_t s, DTensor in, DTensor out);
-void time_mix_v6(hipStream_t s, const uint32_t* cursors, DTensor decay, const void* u_f32, DTensor state, DTensor k, DTensor v, DTensor r, DTensor x);
+void time_mix_v6(hipStream_t s, const uint32_t* cursors, DTensor decay, const void* u_f32, DTensor state, DTensor k, DTensor v, DTensor r, DTensor x,
+                 uint32_t nseq_hint = 0);      // 0: unknown (as many sequences as the state has batches)
 void channel_mix_v6(hipStream_t s, const uint32_t* cursors, DTensor state, DTensor r, DTensor v, DTensor x);
 void binary(hipStream_t s, int is_mul, DTensor in, DTensor out, uint32_t ax, uint32_t ay, uint32_t ao);
 void lerp(hipStream_t s, DTensor x, DTensor y, DTensor f, int reversed);

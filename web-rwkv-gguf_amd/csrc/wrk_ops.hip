@@ -1100,14 +1100,15 @@ static bool dense_f32_heads(const DTensor& d) {
     return d.dtype == WRK_F32 && d.shape[0] == 64 && d.stride[0] == 64 && d.offset[0] == 0 && (((uintptr_t)d.p) & 15u) == 0;
 }
 
-void time_mix_v6(hipStream_t s, const uint32_t* cursors, DTensor decay, const void* u, DTensor st, DTensor k, DTensor v, DTensor r, DTensor x) {
+void time_mix_v6(hipStream_t s, const uint32_t* cursors, DTensor decay, const void* u, DTensor st, DTensor k, DTensor v, DTensor r, DTensor x, uint32_t nseq_hint) {
     if (r.shape[2] == 0) return;
     dim3 grid(r.shape[1], r.shape[2]);
     if (dense_f32_heads(decay) && dense_f32_heads(k) && dense_f32_heads(v) && dense_f32_heads(r) && dense_f16_heads(x) && st.dtype == WRK_F32) {
         const uint32_t T = r.shape[2], slots = std::min(T, st.shape[2]);       // at most one sequence per batch of the state and per token
-        // one wave per head once the sequence slots put a wave on three of four SIMDs (no hint here: as many sequences as the state has batches)
+        // one wave per head once the sequences of the dispatch put a wave on three of four SIMDs (no hint: as many as the state has batches)
         const char* fe = getenv("WRK_WKV_WAVE");
-        const bool wave = fe ? atoi(fe) != 0 : (size_t)slots * r.shape[1] >= 768;
+        const uint32_t nseq = nseq_hint ? std::min(nseq_hint, slots) : slots;
+        const bool wave = fe ? atoi(fe) != 0 : (size_t)nseq * r.shape[1] >= 768;
         if (wave) time_mix_v6_wave_kernel<<<dim3(r.shape[1], slots), 64, 0, s>>>(cursors, decay, (const float*)u, st, k, v, r, x, T);
         else time_mix_v6_fast_kernel<<<dim3(r.shape[1], slots), 256, 0, s>>>(cursors, decay, (const float*)u, st, k, v, r, x, T);
         return;

@@ -26,6 +26,7 @@ struct wrk_v6_model {
     V6Scratch s{};
     uint32_t* history = nullptr;
     size_t history_cap = 0;
+    uint32_t wkv_nseq = 0;      // sequences of the job being enqueued (0: unknown): picks the WKV chunk kernel (wrk::time_mix_v6)
     std::map<std::tuple<const void*, uint32_t, uint32_t>, wrk_program*> graphs;      // (state, sequences, mode)
 
     void drop_graphs() { for (auto& kv : graphs) wrk_program_destroy(kv.second); graphs.clear(); }
@@ -193,7 +194,7 @@ int32_t wrk_v6_model::enqueue_ops(wrk_v7_state* st, uint32_t T, uint32_t NH, boo
         wrk::activate(q, tdec, WRK_ACT_STABLE_EXP);
         wrk::blit(q, att_x, aux_x);
         wrk::time_mix_v6(q, s.cursors, heads(s.time_decay, WRK_F32), L.time_first->ptr, st_att, heads(s.att_k, WRK_F32), heads(s.att_v, WRK_F32),
-                         heads(s.att_r, WRK_F32), heads(s.aux_x));
+                         heads(s.att_r, WRK_F32), heads(s.aux_x), wkv_nseq);
         wrk::group_norm(q, L.gn_w->ptr, L.gn_b->ptr, heads(s.aux_x), GN_EPS);
         wrk::blit(q, aux_x, att_x);
         wrk::binary(q, 1, att_g, att_x, WRK_ACT_SILU, 0, 0);                                              // mul_activate(att_g Silu, att_x)
@@ -646,11 +647,12 @@ int32_t wrk_v6_infer(wrk_ctx* ctx, wrk_v6_model* m, wrk_v7_state* st, const uint
     const uint32_t D = m->d.num_emb, V = m->d.num_vocab;
     std::vector<uint8_t> seen(256, 0);
     bool one_token_each = true;
+    uint32_t nseq = 0;
     for (uint32_t t = 0; t < T; ++t) {
         const uint32_t c = cursors[t], b = c & 0xff, tok = (c >> 8) & 0xffff, len = c >> 24;
         WRK_ARG(ctx, b < st->num_batch, "cursor %u: batch %u >= %u", t, b, st->num_batch);
         WRK_ARG(ctx, len >= 1 && tok <= t && t < tok + len && tok + len <= T, "cursor %u: bad range", t);
-        if (tok == t) { WRK_ARG(ctx, !seen[b], "cursor %u: batch %u appears twice", t, b); seen[b] = 1; }
+        if (tok == t) { WRK_ARG(ctx, !seen[b], "cursor %u: batch %u appears twice", t, b); seen[b] = 1; ++nseq; }
         if (len != 1) one_token_each = false;
         if (tokens) WRK_ARG(ctx, tokens[t] < V, "token %u: id %u >= vocab %u", t, tokens[t], V);
     }
@@ -669,6 +671,7 @@ int32_t wrk_v6_infer(wrk_ctx* ctx, wrk_v6_model* m, wrk_v7_state* st, const uint
         rc = wrk_buf_write_raw(ctx, m->s.input, emb_rows, (size_t)T * D * 2);
         if (rc != WRK_OK) return rc;
     }
+    m->wkv_nseq = nseq;
     rc = WRK_E_UNSUPPORTED;
     if (mode == 1 && one_token_each) rc = m->enqueue_fused_decode(st, T, NH, identity, cursors[0] & 0xff);
     if (rc == WRK_E_UNSUPPORTED) rc = m->enqueue_ops(st, T, NH, identity, mode == 1 && !one_token_each);
