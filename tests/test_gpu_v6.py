@@ -53,12 +53,13 @@ def test_token_shift_per_token_factors_and_transpose(ctx):
     assert np.array_equal(t.back().reshape(5, T, 32), a.transpose(1, 0, 2))
 
 
-@pytest.mark.parametrize("wave", ["0", "1"])
+@pytest.mark.parametrize("wave,octs", [("0", "0"), ("0", "1"), ("1", "0")])
 @pytest.mark.parametrize("lens,H", [([1], 4), ([4, 0, 3], 4), ([7, 1, 13, 4], 2), ([70, 66], 1)])
-def test_time_mix_v6(ctx, lens, H, wave, monkeypatch):
-    # both chunk kernels of the dense layout (WRK_WKV_WAVE: four waves per head | one wave per head, round 3): tails of the 3- / 4-token prefetch
-    # rings, an empty batch, more than 64 stacked tokens
+def test_time_mix_v6(ctx, lens, H, wave, octs, monkeypatch):
+    # the chunk kernels of the dense layout (round 3): four | eight threads per state column (the latter with a head's columns over several
+    # workgroups) | one wave per head: tails of the 3- / 4-token prefetch rings, an empty batch, more than 64 stacked tokens
     monkeypatch.setenv("WRK_WKV_WAVE", wave)
+    monkeypatch.setenv("WRK_WKV_OCT", octs)
     S, B = 64, len(lens)
     D, T = H * S, sum(lens)
     r_ = np.random.default_rng(T)
@@ -95,6 +96,7 @@ def test_time_mix_v6_chunk_kernels_are_bit_identical(ctx, monkeypatch):
     xln = h16(r_.standard_normal((T, D)))
     state = (0.3 * r_.standard_normal((B, S + 2, D))).astype(np.float32)
     got = []
+    monkeypatch.setenv("WRK_WKV_OCT", "0")          # (eight threads per column split each chain of sixteen: equal within the oracle bound only)
     for wave in ("0", "1"):
         monkeypatch.setenv("WRK_WKV_WAVE", wave)
         st, x = ctx.tensor(state), ctx.tensor(xln, [S, H, T])

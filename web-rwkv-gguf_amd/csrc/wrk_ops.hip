@@ -955,26 +955,27 @@ __global__ void __launch_bounds__(256) time_mix_v6_kernel(const uint32_t* __rest
 // Fast path for the runtime's layout (dense f32 decay / k / v / r, f16 x, f32 state): thread (i = tid >> 2, part = tid & 3)
 // owns S[16 part .. +15][i]; the reduction over j is 16 in-register FMAs + two quad shuffles, so a token needs no LDS and
 // no barrier at all (the generic kernel above spends four barriers per token).  Next token's operands are prefetched.
-__global__ void __launch_bounds__(256) time_mix_v6_fast_kernel(const uint32_t* __restrict__ cursors, DTensor decay, const float* __restrict__ u,
+template <int NP>      // threads per state column: 4 (16 rows each) or 8 (8 rows each; few sequences, with the head's columns over blockIdx.z workgroups: as RWKV-7)
+__global__ void __launch_bounds__(64 * NP) time_mix_v6_fast_kernel(const uint32_t* __restrict__ cursors, DTensor decay, const float* __restrict__ u,
                                                                 DTensor st, DTensor k, DTensor v, DTensor r, DTensor x, uint32_t ntok) {
-    constexpr int S = 64;
+    constexpr int S = 64, JJ = S / NP;
     const uint32_t head = blockIdx.x;
     Cursor cur;
     if (!find_sequence(cursors, ntok, blockIdx.y, cur)) return;       // launched over (head, sequence slot), as the RWKV-7 chunk kernels (round 3)
-    const uint32_t tid = threadIdx.x, i = tid >> 2, part = tid & 3u;
+    const uint32_t tid = threadIdx.x, i = blockIdx.z * (blockDim.x / NP) + tid / NP, part = tid % NP;
     const uint32_t ch = head * S + i;
     const uint32_t tend = cur.token + cur.len;
     if (part == 0) dt_store(st, dt_index(st, ch, 0, cur.batch), dt_load(x, dt_index(x, i, head, tend - 1)));
-    float Sreg[16], uu[16];
+    float Sreg[JJ], uu[JJ];
     float* sbase = (float*)st.p;         // f32 state (host-checked): plain loads, all in flight at once
 #pragma unroll
-    for (int jj = 0; jj < 16; ++jj) { Sreg[jj] = sbase[dt_index(st, ch, 1 + part * 16 + jj, cur.batch)]; uu[jj] = u[head * S + part * 16 + jj]; }
-    struct Tok { f32x4 r[4], k[4], w[4]; float v; };
+    for (int jj = 0; jj < JJ; ++jj) { Sreg[jj] = sbase[dt_index(st, ch, 1 + part * JJ + jj, cur.batch)]; uu[jj] = u[head * S + part * JJ + jj]; }
+    struct Tok { f32x4 r[JJ / 4], k[JJ / 4], w[JJ / 4]; float v; };
     const size_t rstep = (size_t)r.stride[1] * r.stride[0], kstep = (size_t)k.stride[1] * k.stride[0];
     const size_t wstep = (size_t)decay.stride[1] * decay.stride[0], vstep = (size_t)v.stride[1] * v.stride[0], xstep = (size_t)x.stride[1] * x.stride[0];
-    const float* rp = (const float*)r.p + dt_index(r, part * 16, head, cur.token);
-    const float* kp = (const float*)k.p + dt_index(k, part * 16, head, cur.token);
-    const float* wp = (const float*)decay.p + dt_index(decay, part * 16, head, cur.token);
+    const float* rp = (const float*)r.p + dt_index(r, part * JJ, head, cur.token);
+    const float* kp = (const float*)k.p + dt_index(k, part * JJ, head, cur.token);
+    const float* wp = (const float*)decay.p + dt_index(decay, part * JJ, head, cur.token);
     const float* vp = (const float*)v.p + dt_index(v, i, head, cur.token);
     f16* xp = (f16*)x.p + dt_index(x, i, head, cur.token);
     // As the RWKV-7 kernel (round 3; this one still had the round-1 form): every load unconditional -- the pointers stop at the last token --,
@@ -985,7 +986,7 @@ __global__ void __launch_bounds__(256) time_mix_v6_fast_kernel(const uint32_t* _
         rp += adv ? rstep : 0; kp += adv ? kstep : 0; wp += adv ? wstep : 0; vp += adv ? vstep : 0;
         lpos += adv ? 1u : 0u;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { T.r[q] = *(const f32x4*)(rp + 4 * q); T.k[q] = *(const f32x4*)(kp + 4 * q); T.w[q] = *(const f32x4*)(wp + 4 * q); }
+        for (int q = 0; q < JJ / 4; ++q) { T.r[q] = *(const f32x4*)(rp + 4 * q); T.k[q] = *(const f32x4*)(kp + 4 * q); T.w[q] = *(const f32x4*)(wp + 4 * q); }
         T.v = *vp;
     };
     constexpr int NPF = 3;
@@ -1001,7 +1002,7 @@ __global__ void __launch_bounds__(256) time_mix_v6_fast_kernel(const uint32_t* _
             const float vv = curT.v;
             float y = 0.0f;
 #pragma unroll
-            for (int jj = 0; jj < 16; ++jj) {
+            for (int jj = 0; jj < JJ; ++jj) {
                 const float kv = curT.k[jj >> 2][jj & 3] * vv;
                 y += curT.r[jj >> 2][jj & 3] * __builtin_fmaf(uu[jj], kv, Sreg[jj]);
                 const float sn = __builtin_fmaf(curT.w[jj >> 2][jj & 3], Sreg[jj], kv);
@@ -1009,13 +1010,14 @@ __global__ void __launch_bounds__(256) time_mix_v6_fast_kernel(const uint32_t* _
             }
             y = y + dpp_f32<0xB1>(y);
             y = y + dpp_f32<0x4E>(y);
+            if (NP == 8) y = y + dpp_f32<0x141>(y);         // the other quad of the column's eight lanes
             if (valid && part == 0) *xp = (f16)y;
             xp += valid ? xstep : 0;
             load_tok(T[q], lpos + 1 < tend);            // this register set is free: token t + NPF (the last one again beyond the chunk; discarded)
         }
     }
 #pragma unroll
-    for (int jj = 0; jj < 16; ++jj) sbase[dt_index(st, ch, 1 + part * 16 + jj, cur.batch)] = Sreg[jj];
+    for (int jj = 0; jj < JJ; ++jj) sbase[dt_index(st, ch, 1 + part * JJ + jj, cur.batch)] = Sreg[jj];
 }
 
 // One wave per (head, sequence), as time_mix_v7_wave_kernel (round 3): lane i owns the state column S[0..63][i]; the per-row operands (decay w, k, r: f32 here)
@@ -1110,7 +1112,19 @@ void time_mix_v6(hipStream_t s, const uint32_t* cursors, DTensor decay, const vo
         const uint32_t nseq = nseq_hint ? std::min(nseq_hint, slots) : slots;
         const bool wave = fe ? atoi(fe) != 0 : (size_t)nseq * r.shape[1] >= 768;
         if (wave) time_mix_v6_wave_kernel<<<dim3(r.shape[1], slots), 64, 0, s>>>(cursors, decay, (const float*)u, st, k, v, r, x, T);
-        else time_mix_v6_fast_kernel<<<dim3(r.shape[1], slots), 256, 0, s>>>(cursors, decay, (const float*)u, st, k, v, r, x, T);
+        else {
+            // few sequences: eight threads per column and the head's columns over 2 or 4 workgroups (the columns never exchange anything), as RWKV-7;
+            // WRK_WKV_OCT=0: four threads per column, one workgroup per head
+            const char* oe = getenv("WRK_WKV_OCT");
+            const uint32_t H = r.shape[1];
+            if (oe && atoi(oe) == 0) time_mix_v6_fast_kernel<4><<<dim3(H, slots), 256, 0, s>>>(cursors, decay, (const float*)u, st, k, v, r, x, T);
+            else {
+                const char* ce = getenv("WRK_WKV_CSPLIT");
+                uint32_t cs = ce ? (uint32_t)atoi(ce) : (nseq * H <= 32 ? 4u : (nseq * H <= 128 ? 2u : 1u));
+                if (cs != 2 && cs != 4) cs = 1;
+                time_mix_v6_fast_kernel<8><<<dim3(H, slots, cs), 512 / cs, 0, s>>>(cursors, decay, (const float*)u, st, k, v, r, x, T);
+            }
+        }
         return;
     }
     time_mix_v6_kernel<<<grid, 256, 0, s>>>(cursors, decay, (const float*)u, st, k, v, r, x);
